@@ -1,0 +1,118 @@
+/*
+ * transoar_msda3d.h -- C ABI of the MI355X (gfx950) 3-D multi-scale deformable
+ * attention operator.  This is the drop-in boundary: the two entry points
+ * below are what the reference's pybind module "MultiScaleDeformableAttention"
+ * exports and what its Python autograd wrapper binds:
+ *
+ *   reference export                         replaced by
+ *   ---------------------------------------  ---------------------------------
+ *   ms_deform_attn_forward                   transoar_msda3d_forward
+ *     ops/src/vision.cpp:14                    (host launcher
+ *     ops/src/ms_deform_attn.h:20-39            ms_deform_attn_cuda.cu:20-80)
+ *   ms_deform_attn_backward                  transoar_msda3d_backward
+ *     ops/src/vision.cpp:15                    (host launcher
+ *     ops/src/ms_deform_attn.h:41-61            ms_deform_attn_cuda.cu:83-154)
+ *
+ * Differences from the reference boundary, on purpose:
+ *   - plain pointers + sizes + a HIP stream; no ATen types.  The caller
+ *     allocates every output (the reference allocates with at::zeros).
+ *   - launch/argument errors are RETURNED (the reference only printf()s kernel
+ *     launch errors, ms_deform_im2col_cuda.cuh:1119-1123).
+ *   - one launch covers the whole batch; im2col_step (a chunking artefact of
+ *     the reference launcher, .cu:50-75) has no meaning here and is not a
+ *     parameter.  The Python shim keeps the argument for API compatibility.
+ *   - 16-bit storage (bf16 / f16) is accepted with fp32 accumulation; the
+ *     reference dispatches float/double only (.cu:64,135).
+ *
+ * Tensor contract (identical to the reference, .cu:40-48):
+ *   value            (N, S, M, C)  contiguous, channel-last; S = sum_l D_l*H_l*W_l
+ *   spatial_shapes   (L, 3) int64  [D, H, W] per level          DEVICE pointer
+ *   level_start_idx  (L,)   int64  first row of each level      DEVICE pointer
+ *   sampling_loc     (N, Lq, M, L, P, 3)  (x, y, z) = (W, H, D) axis, in [0,1]
+ *   attn_weight      (N, Lq, M, L, P)
+ *   out / grad_out   (N, Lq, M*C)
+ * All device buffers must be 16-byte aligned (torch allocations are).
+ * Everything is asynchronous on `stream`; no host synchronisation inside.
+ */
+#ifndef TRANSOAR_MSDA3D_H
+#define TRANSOAR_MSDA3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of device buffers */
+enum {
+  TRANSOAR_F32 = 0,
+  TRANSOAR_F64 = 1,
+  TRANSOAR_BF16 = 2,
+  TRANSOAR_F16 = 3
+};
+
+/* return codes: 0 = success; > 0 = a hipError_t from the launch;
+ * < 0 = argument error detected on the host (see transoar_msda3d_strerror) */
+enum {
+  TRANSOAR_OK = 0,
+  TRANSOAR_ERR_NULL = -1,        /* a required pointer is NULL            */
+  TRANSOAR_ERR_DIM = -2,         /* a dimension is <= 0 or too large      */
+  TRANSOAR_ERR_DTYPE = -3,       /* unsupported dtype combination         */
+  TRANSOAR_ERR_ALIGN = -4,       /* a buffer is not 16-byte aligned       */
+  TRANSOAR_ERR_LEVELS = -5       /* L > TRANSOAR_MSDA3D_MAX_LEVELS        */
+};
+
+#define TRANSOAR_MSDA3D_MAX_LEVELS 8
+
+/* flags (bit set) */
+#define TRANSOAR_MSDA3D_FORCE_GENERIC 1u  /* skip the vectorised kernels   */
+
+/*
+ * Forward.  out[b,q,m*C+c] = sum_{l,p} attn[b,q,m,l,p] *
+ *           trilinear(value_l[b,:,m,c], loc[b,q,m,l,p])   (zero padding,
+ * align_corners=False; a point is skipped unless -1 < coord < size on all
+ * axes).  `out` need not be initialised.
+ *
+ * value_dtype : dtype of value and out.
+ * loc_dtype   : dtype of sampling_loc and attn_weight; must equal value_dtype,
+ *               or be TRANSOAR_F32 when value_dtype is BF16/F16 (the layout
+ *               bf16 autocast produces).
+ * Replaces ms_deform_attn_forward (ops/src/ms_deform_attn.h:20-39).
+ */
+int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index,
+                            const void* sampling_loc, const void* attn_weight,
+                            void* out, int N, int S, int M, int C, int L,
+                            int Lq, int P, int value_dtype, int loc_dtype,
+                            unsigned flags, void* hip_stream);
+
+/*
+ * Backward.  Writes grad_sampling_loc (shape of sampling_loc, loc_dtype) and
+ * grad_attn_weight (shape of attn_weight, loc_dtype) completely, and
+ * ACCUMULATES into grad_value with atomics: the caller must zero grad_value
+ * first (the reference does the same with at::zeros_like, .cu:122).
+ *
+ * grad_value dtype: equal to value_dtype for F32/F64; for BF16/F16 value the
+ * accumulator buffer is F32 (N*S*M*C floats) -- 16-bit atomics would lose the
+ * sum -- and the caller casts afterwards.
+ * Replaces ms_deform_attn_backward (ops/src/ms_deform_attn.h:41-61).
+ */
+int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index,
+                             const void* sampling_loc, const void* attn_weight,
+                             const void* grad_out, void* grad_value,
+                             void* grad_sampling_loc, void* grad_attn_weight,
+                             int N, int S, int M, int C, int L, int Lq, int P,
+                             int value_dtype, int loc_dtype, unsigned flags,
+                             void* hip_stream);
+
+/* Human-readable text for a return code of the functions above. */
+const char* transoar_msda3d_strerror(int code);
+
+/* ABI version of this header: bumped on any signature change. */
+int transoar_msda3d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSOAR_MSDA3D_H */

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only); the GPU
+box never sees the reference, only the .npz files this script wrote.  Every
+vector is produced by the reference's own Python ``use_cuda=False`` path:
+
+  op level      transoar/models/ops/functions/ms_deform_attn_func.py:41-65
+                (ms_deform_attn_core_pytorch) + torch.autograd for gradients
+  module level  transoar/models/ops/modules/ms_deform_attn.py:30-141
+  refine block  transoar/models/backbones/decoder_blocks.py:12-177
+
+The reference's own op test (ops/test.py:69-115) has no committed vectors and
+no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
+"Medium" shape with closed-form (RNG-free) inputs.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from transoar.models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch  # noqa: E402
+from transoar.models.ops.modules import MSDeformAttn  # noqa: E402
+from transoar.models.backbones.decoder_blocks import DecoderDefAttnBlock  # noqa: E402
+from transoar.models.position_encoding import PositionEmbeddingSine3D  # noqa: E402
+
+
+def level_starts(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+
+
+def run_op(value, shapes, loc, attn, grad_seed):
+    value = value.clone().requires_grad_()
+    loc = loc.clone().requires_grad_()
+    attn = attn.clone().requires_grad_()
+    out = ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+    g = torch.Generator().manual_seed(grad_seed)
+    grad_out = torch.randn(out.shape, generator=g, dtype=torch.float64).to(out.dtype)
+    gv, gl, ga = torch.autograd.grad(out, (value, loc, attn), grad_out)
+    return out.detach(), grad_out, gv, gl, ga
+
+
+def pack(prefix, store, value, shapes, loc, attn, grad_seed=1234):
+    out, grad_out, gv, gl, ga = run_op(value, shapes, loc, attn, grad_seed)
+    for k, v in dict(value=value, shapes=shapes, lsi=level_starts(shapes), loc=loc, attn=attn,
+                     out=out, grad_out=grad_out, grad_value=gv, grad_loc=gl, grad_attn=ga).items():
+        store[prefix + "." + k] = v.numpy()
+
+
+def rand_inputs(seed, N, M, C, Lq, L, P, shapes, dtype, loc_lo=0.0, loc_hi=1.0):
+    """ops/test.py:70-73 distributions with a fixed seed."""
+    g = torch.Generator().manual_seed(seed)
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, M, C, generator=g, dtype=torch.float64) * 0.01).to(dtype)
+    loc = (torch.rand(N, Lq, M, L, P, 3, generator=g, dtype=torch.float64) * (loc_hi - loc_lo) + loc_lo).to(dtype)
+    attn = torch.rand(N, Lq, M, L, P, generator=g, dtype=torch.float64) + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype)
+    return value, loc, attn
+
+
+def g1_small():
+    store = {}
+    shapes = torch.as_tensor([(3, 6, 4), (2, 3, 2)], dtype=torch.long)   # ops/test.py:35-37
+    for seed in (0, 1, 2):
+        for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            v, loc, a = rand_inputs(seed, 2, 3, 4, 4, 2, 4, shapes, dt)
+            pack("s%d_%s" % (seed, name), store, v, shapes, loc, a)
+    np.savez_compressed(os.path.join(HERE, "g1_op_small.npz"), **store)
+
+
+def g2_edge():
+    store = {}
+    shapes = torch.as_tensor([(3, 6, 4), (2, 3, 2)], dtype=torch.long)
+    dt = torch.float64
+    # out-of-range locations: zero padding + skipped points
+    v, loc, a = rand_inputs(10, 2, 3, 4, 4, 2, 4, shapes, dt, -0.5, 1.5)
+    pack("oob", store, v, shapes, loc, a)
+    # float32 copy of the same
+    pack("oob_f32", store, v.float(), shapes, loc.float(), a.float())
+    # locations exactly on voxel centres (integer pixel coordinates: one corner
+    # carries the whole weight -- the model's init state, ms_deform_attn.py:67-82)
+    v, loc, a = rand_inputs(11, 2, 3, 4, 4, 2, 4, shapes, dt)
+    g = torch.Generator().manual_seed(12)
+    for lvl, (D, H, W) in enumerate(shapes.tolist()):
+        idx = torch.stack([torch.randint(0, W, (2, 4, 3, 4), generator=g),
+                           torch.randint(0, H, (2, 4, 3, 4), generator=g),
+                           torch.randint(0, D, (2, 4, 3, 4), generator=g)], -1).double()
+        loc[:, :, :, lvl] = (idx + 0.5) / torch.tensor([W, H, D], dtype=dt)
+    pack("centres", store, v, shapes, loc, a)
+    # locations on the borders {0,1}
+    v, loc, a = rand_inputs(13, 2, 3, 4, 4, 2, 4, shapes, dt)
+    loc = (loc > 0.5).to(dt)
+    pack("border", store, v, shapes, loc, a)
+    # L=1, P=1
+    sh1 = torch.as_tensor([(2, 2, 2)], dtype=torch.long)
+    v, loc, a = rand_inputs(14, 1, 1, 1, 1, 1, 1, sh1, dt)
+    pack("tiny", store, v, sh1, loc, a)
+    # channel counts that hit every backward variant of the reference
+    # (ops/test.py:122: 1..10,32,64..71,...) -- a representative subset
+    for C in (1, 3, 5, 32, 64, 65):
+        v, loc, a = rand_inputs(20 + C, 2, 3, C, 4, 2, 4, shapes, dt, -0.1, 1.1)
+        pack("c%d" % C, store, v, shapes, loc, a)
+    np.savez_compressed(os.path.join(HERE, "g2_op_edge.npz"), **store)
+
+
+def medium_inputs(dtype=torch.float64):
+    """Closed-form, RNG-free inputs for ops/test.py's "Medium" shape (:28-31)."""
+    N, M, C, Lq, L, P = 1, 16, 16, 4860, 3, 4
+    shapes = torch.as_tensor([(8, 15, 39), (4, 4, 10), (2, 2, 5)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    i = torch.arange(N * S * M * C, dtype=torch.float64).reshape(N, S, M, C)
+    value = 0.01 * (0.5 + 0.5 * torch.sin(0.37 * i + 0.11 * torch.sqrt(i + 1.0)))
+    j = torch.arange(N * Lq * M * L * P * 3, dtype=torch.float64).reshape(N, Lq, M, L, P, 3)
+    loc = -0.1 + 1.2 * (0.5 + 0.5 * torch.cos(1.93 * j + 0.007 * j ** 1.5 / (1.0 + 1e-4 * j)))
+    k = torch.arange(N * Lq * M * L * P, dtype=torch.float64).reshape(N, Lq, M, L, P)
+    attn = 1.0 + torch.sin(0.77 * k) ** 2
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    return value.to(dtype), shapes, loc.to(dtype), attn.to(dtype)
+
+
+def g3_medium():
+    value, shapes, loc, attn = medium_inputs()
+    out, grad_out, gv, gl, ga = run_op(value, shapes, loc, attn, 99)
+    # inputs are regenerated by the test from the same closed form
+    # (tests/_inputs.py:medium_inputs); store every 8th output row + checksums
+    np.savez_compressed(
+        os.path.join(HERE, "g3_op_medium.npz"),
+        out_rows=out[:, ::8].numpy(), out_sum=np.float64(out.sum().item()),
+        out_abs_sum=np.float64(out.abs().sum().item()),
+        grad_out_sum=np.float64(grad_out.sum().item()),
+        grad_value_sum=np.float64(gv.sum().item()), grad_value_abs_sum=np.float64(gv.abs().sum().item()),
+        grad_loc_sum=np.float64(gl.sum().item()), grad_loc_abs_sum=np.float64(gl.abs().sum().item()),
+        grad_attn_sum=np.float64(ga.sum().item()), grad_attn_abs_sum=np.float64(ga.abs().sum().item()),
+        grad_value_head=gv.flatten()[:4096].numpy(), grad_loc_head=gl.flatten()[:4096].numpy(),
+        grad_attn_head=ga.flatten()[:4096].numpy(),
+    )
+
+
+def state_np(module):
+    return {k: v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+def g4_module():
+    torch.manual_seed(4)
+    d_model, L, M, P = 48, 2, 6, 4
+    mod = MSDeformAttn(d_model, L, M, P, use_cuda=False).double()
+    # move the weights off their (mostly zero) init so every path is exercised
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.05)
+        mod.attention_weights.weight.normal_(0, 0.3)
+        mod.attention_weights.bias.normal_(0, 0.3)
+        mod.value_proj.bias.normal_(0, 0.1)
+        mod.output_proj.bias.normal_(0, 0.1)
+    shapes = torch.as_tensor([(3, 4, 5), (2, 2, 3)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    N = 2
+    query = torch.randn(N, S, d_model, dtype=torch.float64)
+    src = torch.randn(N, S, d_model, dtype=torch.float64)
+    ref = torch.rand(N, S, L, 3, dtype=torch.float64)
+    y = mod(query, ref, src, shapes, level_starts(shapes))
+    gy = torch.randn_like(y)
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(y, list(params.values()), gy)
+    store = {"state." + k: v for k, v in state_np(mod).items()}
+    store.update({"grad." + k: g.numpy() for k, g in zip(params, grads)})
+    store.update(query=query.numpy(), src=src.numpy(), ref=ref.numpy(), shapes=shapes.numpy(),
+                 y=y.detach().numpy(), gy=gy.numpy())
+    np.savez_compressed(os.path.join(HERE, "g4_module.npz"), **store)
+
+
+def g5_refine_block():
+    """BASELINE.json config #1 restated: the refine block on the
+    pyramid a 32^3 volume gives at P3/P4/P5 = (4,4,4),(2,2,2),(1,1,1)."""
+    torch.manual_seed(5)
+    d_model = 48
+    blk = DecoderDefAttnBlock(d_model=d_model, nhead=6, num_layers=2, dim_feedforward=64, dropout=0.1,
+                              feature_levels=["P3", "P4", "P5"], n_points=4, use_cuda=False).double().eval()
+    with torch.no_grad():
+        for layer in blk.refine_def_attn.layers:
+            layer.self_attn.sampling_offsets.weight.normal_(0, 0.05)
+            layer.self_attn.attention_weights.weight.normal_(0, 0.3)
+    pos_enc = PositionEmbeddingSine3D(channels=d_model)
+    fmaps = [torch.rand(1, d_model, s, s, s, dtype=torch.float64) for s in (4, 2, 1)]
+    pos = [pos_enc(f).double() for f in fmaps]
+    outs = blk(fmaps, pos)
+    store = {"state." + k: v for k, v in state_np(blk).items()}
+    for i, (f, p, o) in enumerate(zip(fmaps, pos, outs)):
+        store["fmap%d" % i] = f.numpy()
+        store["pos%d" % i] = p.numpy()
+        store["out%d" % i] = o.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_refine_block.npz"), **store)
+
+
+if __name__ == "__main__":
+    g1_small()
+    g2_edge()
+    g3_medium()
+    g4_module()
+    g5_refine_block()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI shared library builds/loads, exports every symbol the
+header declares, and validates arguments on the host (no kernel is launched
+here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "transoar_msda3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(transoar_msda3d_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = _declared_symbols()
+    assert "transoar_msda3d_forward" in syms and "transoar_msda3d_backward" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from transoar_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+    assert _native.lib.transoar_msda3d_abi_version() == _native.ABI_VERSION
+
+
+def test_argument_errors_are_returned_not_printed():
+    from transoar_amd import _native
+    lib = _native.lib
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    dims_ok = (1, 8, 1, 4, 1, 1, 1)
+    # NULL pointer
+    assert lib.transoar_msda3d_forward(None, p16, p16, p16, p16, p16, *dims_ok, 0, 0, 0, None) == -1
+    # bad dimension
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 0, 1, 1, 1, 0, 0, 0, None) == -2
+    # dtype combination: f32 value with f64 loc
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, *dims_ok, 0, 1, 0, None) == -3
+    # bf16 value with fp32 loc is legal as far as dtype goes; misaligned buffer
+    assert lib.transoar_msda3d_forward(p16 + 4, p16, p16, p16, p16, p16, *dims_ok, 2, 0, 0, None) == -4
+    # too many levels
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 4, 9, 1, 1, 0, 0, 0, None) == -5
+    assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, None, p16, p16, p16, *dims_ok, 0, 0, 0, None) == -1
+    for code in (0, -1, -2, -3, -4, -5):
+        assert len(lib.transoar_msda3d_strerror(code)) > 0
+
+
+def test_cpu_tensors_raise_like_the_reference():
+    """ops/src/ms_deform_attn.h:38: "Not implemented on the CPU"."""
+    import torch
+    from transoar_amd import MSDA
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(torch.zeros(1, 8, 1, 4), torch.tensor([[2, 2, 2]]), torch.tensor([0]),
+                                    torch.zeros(1, 1, 1, 1, 1, 3), torch.zeros(1, 1, 1, 1, 1), 64)
+
+
+def test_use_cuda_false_needs_an_injected_core():
+    import torch
+    from transoar_amd import MSDeformAttn
+    from transoar_amd import ms_deform_attn as mod
+    prev = mod.register_debug_core(None)
+    try:
+        m = MSDeformAttn(12, 1, 6, 1, use_cuda=False)
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            m(torch.zeros(1, 8, 12), torch.zeros(1, 8, 1, 3), torch.zeros(1, 8, 12),
+              torch.tensor([[2, 2, 2]]), torch.tensor([0]))
+    finally:
+        mod.register_debug_core(prev)

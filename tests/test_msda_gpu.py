@@ -1,0 +1,276 @@
+"""GPU: the gfx950 kernels, called through the MSDA boundary (ctypes -> C ABI),
+against the golden vectors, the scalar C oracle and the torch restatement.
+
+Tolerances (stated, per BASELINE.json north_star "<=1e-4 max rel-err, fp32"):
+  fp64  1e-10 relative to the tensor's max magnitude (summation order only)
+  fp32  1e-4  relative to the tensor's max magnitude; observed ~1e-6
+  bf16/f16 storage with fp32 accumulation: inputs are rounded to the storage
+        type first and the oracle runs on those rounded inputs in fp32, so the
+        only extra error is the output rounding: 2^-8 (bf16) / 2^-11 (f16) rel.
+grad_value is accumulated with float atomics: order varies run to run, the
+tolerance covers it.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda3d_oracle as c_oracle
+from oracle.torch_ref import msda3d_core_torch
+from tests import _inputs
+from tests._inputs import case_prefixes, level_starts, load_case, medium_inputs, rand_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def MSDA():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import MSDA as m
+    return m
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-300)
+
+
+TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+
+
+def run_gpu(MSDA, c, dtype=None, loc_dtype=None, backward=True):
+    dev = "cuda"
+    dtype = dtype or c["value"].dtype
+    loc_dtype = loc_dtype or dtype
+    v = c["value"].to(dtype).to(dev)
+    loc = c["loc"].to(loc_dtype).to(dev)
+    a = c["attn"].to(loc_dtype).to(dev)
+    sh, lsi = c["shapes"].to(dev), c["lsi"].to(dev)
+    out = MSDA.ms_deform_attn_forward(v, sh, lsi, loc, a, 64)
+    if not backward:
+        return out, None
+    go = c["grad_out"].to(dtype).to(dev)
+    grads = MSDA.ms_deform_attn_backward(v, sh, lsi, loc, a, go, 64)
+    torch.cuda.synchronize()
+    return out, grads
+
+
+@pytest.mark.parametrize("fixture", ["g1_op_small.npz", "g2_op_edge.npz"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_golden_vectors(MSDA, golden_dir, fixture, generic):
+    z = np.load(os.path.join(golden_dir, fixture))
+    MSDA.flags = 1 if generic else 0
+    try:
+        for prefix in case_prefixes(z):
+            c = load_case(z, prefix)
+            dt = c["value"].dtype
+            out, (gv, gl, ga) = run_gpu(MSDA, c)
+            tol = TOL[dt]
+            assert out.dtype == dt and tuple(out.shape) == tuple(c["out"].shape)
+            assert relerr(out, c["out"]) <= tol, (prefix, "out")
+            assert relerr(gv, c["grad_value"]) <= tol, (prefix, "grad_value")
+            assert relerr(ga, c["grad_attn"]) <= tol, (prefix, "grad_attn")
+            if prefix != "centres":   # not differentiable there, see tests/test_oracle.py
+                assert relerr(gl, c["grad_loc"]) <= tol, (prefix, "grad_loc")
+            else:
+                # same formula and same fp rounding of the pixel coordinate as
+                # the scalar oracle -> same one-sided derivative
+                _, olg, _ = c_oracle.backward(*[c[k].numpy() for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out")])
+                assert relerr(gl, torch.from_numpy(olg)) <= tol, (prefix, "grad_loc vs C oracle")
+    finally:
+        MSDA.flags = 0
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_medium_shape(MSDA, golden_dir, generic):
+    z = np.load(os.path.join(golden_dir, "g3_op_medium.npz"))
+    MSDA.flags = 1 if generic else 0
+    try:
+        for dt in (torch.float64, torch.float32):
+            value, shapes, loc, attn = medium_inputs(dt)
+            g = torch.Generator().manual_seed(99)
+            grad_out = torch.randn((1, 4860, 256), generator=g, dtype=torch.float64).to(dt)
+            c = dict(value=value, shapes=shapes, lsi=level_starts(shapes), loc=loc, attn=attn, grad_out=grad_out)
+            out, (gv, gl, ga) = run_gpu(MSDA, c)
+            tol = TOL[dt]
+            assert relerr(out[:, ::8], torch.from_numpy(z["out_rows"])) <= tol
+            assert abs(out.double().sum().item() - float(z["out_sum"])) <= tol * float(z["out_abs_sum"])
+            for name, arr in (("grad_value", gv), ("grad_loc", gl), ("grad_attn", ga)):
+                assert abs(arr.double().sum().item() - float(z[name + "_sum"])) <= tol * float(z[name + "_abs_sum"]), name
+                assert relerr(arr.flatten()[:4096], torch.from_numpy(z[name + "_head"])) <= 10 * tol, name
+    finally:
+        MSDA.flags = 0
+
+
+# channel counts of the reference's gradcheck sweep (ops/test.py:122) that matter
+# here: vector path (16/32/64/128 per dtype), odd counts, > 64 (multi-pass lanes)
+@pytest.mark.parametrize("C", [1, 2, 3, 5, 8, 16, 32, 64, 65, 71, 128, 256, 1025])
+def test_channel_sweep_fp64_vs_c_oracle(MSDA, C):
+    shapes = torch.as_tensor([(3, 6, 4), (2, 3, 2)], dtype=torch.long)
+    v, loc, a = rand_inputs(100 + C, 2, 3, C, 4, 2, 4, shapes, torch.float64, -0.1, 1.1)
+    lsi = level_starts(shapes)
+    g = torch.Generator().manual_seed(C)
+    go = torch.randn(2, 4, 3 * C, generator=g, dtype=torch.float64)
+    c = dict(value=v, shapes=shapes, lsi=lsi, loc=loc, attn=a, grad_out=go)
+    out, (gv, gl, ga) = run_gpu(MSDA, c)
+    ro = c_oracle.forward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy())
+    rgv, rgl, rga = c_oracle.backward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy(), go.numpy())
+    assert relerr(out, torch.from_numpy(ro)) <= 1e-12
+    assert relerr(gv, torch.from_numpy(rgv)) <= 1e-12
+    assert relerr(gl, torch.from_numpy(rgl)) <= 1e-12
+    assert relerr(ga, torch.from_numpy(rga)) <= 1e-12
+
+
+@pytest.mark.parametrize("C", [4, 64])
+def test_gradcheck_fp64(MSDA, C):
+    """The reference's own gradient test (ops/test.py:100-115) on our op."""
+    from transoar_amd import MSDeformAttnFunction
+    shapes = torch.as_tensor([(3, 6, 4), (2, 3, 2)], dtype=torch.long)
+    v, loc, a = rand_inputs(7, 2, 3, C, 4, 2, 4, shapes, torch.float64)
+    dev = "cuda"
+    v = v.to(dev).requires_grad_()
+    loc = loc.to(dev).requires_grad_()
+    a = a.to(dev).requires_grad_()
+    assert torch.autograd.gradcheck(
+        MSDeformAttnFunction.apply, (v, shapes.to(dev), level_starts(shapes).to(dev), loc, a, 2),
+        nondet_tol=1e-12)
+
+
+@pytest.mark.parametrize("vdt,ldt", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.float16, torch.float32), (torch.float16, torch.float16)])
+@pytest.mark.parametrize("C", [64, 32, 8])
+def test_half_storage_fp32_accumulate(MSDA, vdt, ldt, C):
+    shapes = torch.as_tensor([(5, 6, 7), (3, 3, 4), (2, 2, 2)], dtype=torch.long)
+    v, loc, a = rand_inputs(5, 2, 6, C, 50, 3, 4, shapes, torch.float32, -0.05, 1.05)
+    v = (v * 100).to(vdt)
+    loc, a = loc.to(ldt), a.to(ldt)
+    lsi = level_starts(shapes)
+    g = torch.Generator().manual_seed(3)
+    go = torch.randn(2, 50, 6 * C, generator=g).to(vdt)
+    c = dict(value=v, shapes=shapes, lsi=lsi, loc=loc, attn=a, grad_out=go)
+    out, (gv, gl, ga) = run_gpu(MSDA, c, dtype=vdt, loc_dtype=ldt)
+    assert out.dtype == vdt and gv.dtype == vdt and gl.dtype == ldt and ga.dtype == ldt
+    # oracle in fp32 on the rounded inputs
+    f = lambda t: t.float().numpy()
+    ro = c_oracle.forward(f(v), shapes.numpy(), lsi.numpy(), f(loc), f(a))
+    rgv, rgl, rga = c_oracle.backward(f(v), shapes.numpy(), lsi.numpy(), f(loc), f(a), f(go))
+    tv, tl = TOL[vdt], (TOL[ldt] if ldt != torch.float32 else 1e-4)
+    assert relerr(out, torch.from_numpy(ro)) <= tv
+    assert relerr(gv, torch.from_numpy(rgv)) <= tv
+    assert relerr(gl, torch.from_numpy(rgl)) <= tl
+    assert relerr(ga, torch.from_numpy(rga)) <= tl
+
+
+def test_ragged_and_degenerate_shapes(MSDA):
+    """L=1,P=1; one query; P not dividing the 16-point chunk; L*P > 16."""
+    for (N, M, C, Lq, levels, P) in [(1, 1, 64, 1, [(1, 1, 1)], 1), (3, 6, 64, 7, [(2, 3, 4)], 5),
+                                     (1, 2, 64, 9, [(4, 4, 4), (2, 2, 2), (1, 1, 1)], 7),
+                                     (2, 6, 64, 33, [(4, 5, 6), (3, 3, 3), (2, 2, 2), (1, 2, 1), (1, 1, 1)], 4)]:
+        shapes = torch.as_tensor(levels, dtype=torch.long)
+        v, loc, a = rand_inputs(1, N, M, C, Lq, len(levels), P, shapes, torch.float32, -0.2, 1.2)
+        lsi = level_starts(shapes)
+        go = torch.randn(N, Lq, M * C, generator=torch.Generator().manual_seed(2))
+        c = dict(value=v, shapes=shapes, lsi=lsi, loc=loc, attn=a, grad_out=go)
+        out, (gv, gl, ga) = run_gpu(MSDA, c)
+        ro = c_oracle.forward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy())
+        rgv, rgl, rga = c_oracle.backward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy(), go.numpy())
+        for got, ref in ((out, ro), (gv, rgv), (gl, rgl), (ga, rga)):
+            assert relerr(got, torch.from_numpy(ref)) <= 1e-5, (N, M, C, Lq, levels, P)
+
+
+def test_all_points_outside_gives_zero(MSDA):
+    shapes = torch.as_tensor([(3, 3, 3)], dtype=torch.long)
+    v, loc, a = rand_inputs(1, 1, 6, 64, 5, 1, 4, shapes, torch.float32)
+    loc = loc + 2.0
+    c = dict(value=v, shapes=shapes, lsi=level_starts(shapes), loc=loc, attn=a,
+             grad_out=torch.ones(1, 5, 6 * 64))
+    out, (gv, gl, ga) = run_gpu(MSDA, c)
+    assert float(out.abs().max()) == 0 and float(gv.abs().max()) == 0
+    assert float(gl.abs().max()) == 0 and float(ga.abs().max()) == 0
+
+
+def test_contiguity_and_batch_checks(MSDA):
+    shapes = torch.as_tensor([(2, 2, 2)], dtype=torch.long).cuda()
+    v = torch.zeros(3, 8, 6, 64, device="cuda")
+    loc = torch.zeros(3, 4, 6, 1, 2, 3, device="cuda")
+    a = torch.zeros(3, 4, 6, 1, 2, device="cuda")
+    lsi = torch.zeros(1, dtype=torch.long, device="cuda")
+    with pytest.raises(RuntimeError, match="contiguous"):
+        MSDA.ms_deform_attn_forward(v.transpose(0, 1).contiguous().transpose(0, 1), shapes, lsi, loc, a, 64)
+    with pytest.raises(RuntimeError, match="must divide"):     # .cu:52
+        MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, a, 2)
+    MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, a, 3)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full size: N=2, S=Lq=117000, M=6, C=64, L=4, P=4 -- properties
+# that do not need a full-size CPU oracle run.
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def flagship():
+    return _inputs.model_like_inputs(0, 2, _inputs.VISCERAL_LEVELS, device="cuda")
+
+
+def test_flagship_sampled_queries_vs_torch_oracle(MSDA, flagship):
+    value, shapes, lsi, loc, attn = flagship
+    out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64)
+    g = torch.Generator().manual_seed(0)
+    pick = torch.randint(0, loc.shape[1], (512,), generator=g)
+    ref = msda3d_core_torch(value.cpu(), shapes.cpu(), loc[:, pick].cpu(), attn[:, pick].cpu())
+    assert relerr(out[:, pick], ref) <= 1e-4
+
+
+def test_flagship_partition_of_unity_and_linearity(MSDA, flagship):
+    value, shapes, lsi, loc, attn = flagship
+    # interior points only -> the 8 corner weights sum to 1; attn sums to 1
+    loc_in = loc.clamp(0.3, 0.7)
+    ones = torch.ones_like(value)
+    out1 = MSDA.ms_deform_attn_forward(ones, shapes, lsi, loc_in, attn, 64)
+    assert float((out1 - 1).abs().max()) <= 1e-5
+    # linear in value and in attn
+    o_a = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64)
+    o_b = MSDA.ms_deform_attn_forward(2 * value + ones, shapes, lsi, loc_in, attn, 64)
+    o_c = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc_in, attn, 64)
+    assert relerr(o_b, 2 * o_c + 1) <= 1e-5
+    assert relerr(MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, 0.5 * attn, 64), 0.5 * o_a) <= 1e-6
+
+
+def test_flagship_identity_gather(MSDA, flagship):
+    """One-hot attention on a point that sits on the query's own voxel centre
+    returns value itself (Lq == S)."""
+    value, shapes, lsi, loc, attn = flagship
+    ref = _inputs.reference_points(shapes.cpu()).to("cuda")                 # (1,S,3)
+    loc_id = loc.clone()
+    # level of each query = the level its own row lives in
+    S = value.shape[1]
+    lvl = torch.bucketize(torch.arange(S, device="cuda"), lsi[1:], right=True)
+    attn_id = torch.zeros_like(attn)
+    for l in range(shapes.shape[0]):
+        sel = lvl == l
+        loc_id[:, sel, :, l, 0, :] = ref[:, sel, None, :]
+        attn_id[:, sel, :, l, 0] = 1.0
+    out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc_id, attn_id, 64)
+    assert relerr(out, value.flatten(2)) <= 1e-5
+
+
+def test_flagship_backward_mass_conservation(MSDA, flagship):
+    """sum_s grad_value[b,s,m,c] == sum_q grad_out[b,q,m,c] when every point is
+    interior (corner weights sum to 1) and attn sums to 1; plus sampled rows of
+    grad_loc/grad_attn against the torch oracle's autograd."""
+    value, shapes, lsi, loc, attn = flagship
+    loc_in = loc.clamp(0.3, 0.7).contiguous()
+    go = torch.randn(value.shape[0], loc.shape[1], 6 * 64, device="cuda",
+                     generator=torch.Generator(device="cuda").manual_seed(1))
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc_in, attn, go, 64)
+    lhs = gv.double().sum(1).flatten(1)
+    rhs = go.double().sum(1)
+    assert relerr(lhs, rhs) <= 1e-4
+    pick = torch.randint(0, loc.shape[1], (256,), generator=torch.Generator().manual_seed(5))
+    lc = loc_in[:, pick].cpu().requires_grad_()
+    ac = attn[:, pick].cpu().requires_grad_()
+    ref = msda3d_core_torch(value.cpu(), shapes.cpu(), lc, ac)
+    rgl, rga = torch.autograd.grad(ref, (lc, ac), go[:, pick].cpu())
+    assert relerr(gl[:, pick], rgl) <= 1e-4
+    assert relerr(ga[:, pick], rga) <= 1e-4

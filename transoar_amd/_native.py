@@ -1,0 +1,55 @@
+"""ctypes binding of the C ABI declared in include/transoar_msda3d.h.
+
+There is deliberately NO fallback: if the gfx950 library is missing or does
+not export the ABI, importing this module raises.  A missing build must never
+turn into a silently slower (or CPU) path.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libtransoar_msda3d.so"
+
+F32, F64, BF16, F16 = 0, 1, 2, 3
+FORCE_GENERIC = 1
+ABI_VERSION = 1
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def _load():
+    path = os.path.join(_PKG, _LIB_NAME)
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m transoar_amd._build`) in the repository root; there is no "
+            "fallback implementation." % path)
+    lib = ctypes.CDLL(path)
+    c_int, c_void_p, c_uint = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint
+    try:
+        lib.transoar_msda3d_forward.restype = c_int
+        lib.transoar_msda3d_forward.argtypes = [c_void_p] * 6 + [c_int] * 9 + [c_uint, c_void_p]
+        lib.transoar_msda3d_backward.restype = c_int
+        lib.transoar_msda3d_backward.argtypes = [c_void_p] * 9 + [c_int] * 9 + [c_uint, c_void_p]
+        lib.transoar_msda3d_strerror.restype = ctypes.c_char_p
+        lib.transoar_msda3d_strerror.argtypes = [c_int]
+        lib.transoar_msda3d_abi_version.restype = c_int
+        lib.transoar_msda3d_abi_version.argtypes = []
+    except AttributeError as e:  # symbol missing
+        raise NativeLibraryError("%s does not export the transoar_msda3d ABI: %s" % (path, e))
+    got = lib.transoar_msda3d_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryError("%s has ABI version %d, expected %d: rebuild" % (path, got, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+LIB_PATH = os.path.join(_PKG, _LIB_NAME)
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (
+            what, lib.transoar_msda3d_strerror(code).decode(), code))

@@ -1,0 +1,186 @@
+// Shared device helpers for the gfx950 MSDeformAttn-3D kernels.
+// wave = 64 lanes everywhere in this directory (CDNA4); no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace transoar {
+
+struct bf16_t { unsigned short bits; };
+struct f16_t { _Float16 v; };
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+  return __uint_as_float(static_cast<unsigned int>(b) << 16);
+}
+// round-to-nearest-even, NaN kept quiet (matches torch's float->bfloat16)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+
+// Storage-type traits: accumulator type, elements per 16-byte lane vector,
+// scalar load/store and 16-byte vector load/store with conversion.
+template <typename T> struct Elem;
+
+template <> struct Elem<float> {
+  using acc = float;
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void unpack(const u32x4& r, float (&o)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(r[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&o)[4]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(o[i]);
+    return r;
+  }
+};
+
+template <> struct Elem<double> {
+  using acc = double;
+  static constexpr int VEC = 2;
+  static __device__ __forceinline__ double ld(const double* p) { return *p; }
+  static __device__ __forceinline__ void st(double* p, double v) { *p = v; }
+  static __device__ __forceinline__ void unpack(const u32x4& r, double (&o)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      o[i] = __longlong_as_double((static_cast<long long>(r[2 * i + 1]) << 32) |
+                                  static_cast<long long>(r[2 * i]));
+  }
+  static __device__ __forceinline__ u32x4 pack(const double (&o)[2]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long b = __double_as_longlong(o[i]);
+      r[2 * i] = static_cast<unsigned int>(b);
+      r[2 * i + 1] = static_cast<unsigned int>(b >> 32);
+    }
+    return r;
+  }
+};
+
+template <> struct Elem<bf16_t> {
+  using acc = float;
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+  static __device__ __forceinline__ void unpack(const u32x4& r, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(r[i] << 16);
+      o[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&o)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      r[i] = static_cast<unsigned int>(f32_to_bf16(o[2 * i])) |
+             (static_cast<unsigned int>(f32_to_bf16(o[2 * i + 1])) << 16);
+    return r;
+  }
+};
+
+template <> struct Elem<f16_t> {
+  using acc = float;
+  static constexpr int VEC = 8;
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  static __device__ __forceinline__ float ld(const f16_t* p) { return static_cast<float>(p->v); }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { p->v = static_cast<_Float16>(v); }
+  static __device__ __forceinline__ void unpack(const u32x4& r, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const h2 h = __builtin_bit_cast(h2, r[i]);
+      o[2 * i] = static_cast<float>(h[0]);
+      o[2 * i + 1] = static_cast<float>(h[1]);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&o)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h2 h;
+      h[0] = static_cast<_Float16>(o[2 * i]);
+      h[1] = static_cast<_Float16>(o[2 * i + 1]);
+      r[i] = __builtin_bit_cast(unsigned int, h);
+    }
+    return r;
+  }
+};
+
+// pixel coordinate of a normalised location: loc*size - 0.5 with the multiply
+// and the subtract rounded separately (no FMA contraction), so floor() picks
+// the same cell as the scalar oracle (oracle/msda3d_oracle_impl.h) bit for bit.
+__device__ __forceinline__ float pixel_coord(float loc, int size) {
+  return __fsub_rn(__fmul_rn(loc, static_cast<float>(size)), 0.5f);
+}
+__device__ __forceinline__ double pixel_coord(double loc, int size) {
+  return __dsub_rn(__dmul_rn(loc, static_cast<double>(size)), 0.5);
+}
+
+// wave-uniform broadcast of lane `src`'s value (src must be wave-uniform)
+__device__ __forceinline__ float bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double bcast(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(b), src);
+  const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), src);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | lo);
+}
+
+__device__ __forceinline__ float xor_lanes(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double xor_lanes(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// hardware fp atomics (no CAS loop): compiled with -munsafe-fp-atomics
+__device__ __forceinline__ void atomic_accum(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_accum(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum-transpose of 64 per-lane partials over the 64 lanes of a wave: on return
+// lane r holds  sum over lanes of v[r].  63 exchange+add steps (vs 64*6 for 64
+// separate butterflies).  Each fold writes a fresh array: folding in place
+// keeps hipcc (ROCm 7.2) from promoting the 64-float array to registers
+// (272 B/lane of scratch instead).
+template <int HALF, typename A>
+__device__ __forceinline__ void fold_lanes(const A (&in)[2 * HALF], A (&out)[HALF], int lane) {
+  const bool up = (lane & HALF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const A send = up ? in[i] : in[i + HALF];
+    const A keep = up ? in[i + HALF] : in[i];
+    out[i] = keep + xor_lanes(send, HALF);
+  }
+}
+template <typename A>
+__device__ __forceinline__ A sum_transpose64(const A (&v)[64], int lane) {
+  A a32[32], a16[16], a8[8], a4[4], a2[2], a1[1];
+  fold_lanes<32>(v, a32, lane);
+  fold_lanes<16>(a32, a16, lane);
+  fold_lanes<8>(a16, a8, lane);
+  fold_lanes<4>(a8, a4, lane);
+  fold_lanes<2>(a4, a2, lane);
+  fold_lanes<1>(a2, a1, lane);
+  return a1[0];
+}
+
+// Observed (not contractual) placement: block b runs on XCD b % 8.  Remap so
+// each XCD walks one contiguous eighth of the work and neighbouring query
+// blocks share that XCD's L2.  Returns -1 for the padding blocks.
+__device__ __forceinline__ long xcd_contiguous_block(long bid, long nblk) {
+  const long per = (nblk + 7) >> 3;
+  const long swz = (bid & 7) * per + (bid >> 3);
+  return swz < nblk ? swz : -1;
+}
+
+}  // namespace transoar

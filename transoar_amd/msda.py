@@ -1,0 +1,126 @@
+"""The ``MSDA`` object: the two functions the reference's pybind module
+``MultiScaleDeformableAttention`` exports (ops/src/vision.cpp:13-16), bound to
+the gfx950 C ABI instead of the CUDA extension.
+
+    import transoar_amd.msda as MSDA
+    out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, im2col_step)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_out, im2col_step)
+
+Argument order, layouts, the contiguity / device checks and the returned shapes
+follow ops/src/cuda/ms_deform_attn_cuda.cu:20-80 (forward) and :83-154
+(backward).  Differences: bf16/f16 storage is accepted (fp32 accumulate; the
+reference dispatches float/double only, .cu:64), kernel launch errors raise
+(the reference printf()s them, ms_deform_im2col_cuda.cuh:1119-1123), and
+``im2col_step`` only takes part in the reference's divisibility check -- the
+batch is processed in one launch.
+"""
+import torch
+
+from . import _native
+
+_DT = {torch.float32: _native.F32, torch.float64: _native.F64,
+       torch.bfloat16: _native.BF16, torch.float16: _native.F16}
+
+# bit set forwarded to the C ABI (see include/transoar_msda3d.h); module-level so
+# tests can force the generic kernels.
+flags = 0
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_inputs(named):
+    for name, t in named:
+        _require(t.is_contiguous(), "%s tensor has to be contiguous" % name)
+    if not named[0][1].is_cuda:
+        # ops/src/ms_deform_attn.h:38,60
+        raise RuntimeError("Not implemented on the CPU")
+    dev = named[0][1].device
+    for name, t in named:
+        _require(t.is_cuda and t.device == dev, "%s must be a CUDA tensor on %s" % (name, dev))
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    _require(value.dim() == 4, "value must be (N, S, M, C)")
+    _require(sampling_loc.dim() == 6 and sampling_loc.size(-1) == 3,
+             "sampling_loc must be (N, Lq, M, L, P, 3)")
+    N, S, M, C = value.shape
+    L = spatial_shapes.size(0)
+    Lq, P = sampling_loc.size(1), sampling_loc.size(4)
+    _require(spatial_shapes.dtype == torch.int64 and tuple(spatial_shapes.shape) == (L, 3),
+             "spatial_shapes must be int64 (L, 3)")
+    _require(level_start_index.dtype == torch.int64 and tuple(level_start_index.shape) == (L,),
+             "level_start_index must be int64 (L,)")
+    _require(tuple(sampling_loc.shape) == (N, Lq, M, L, P, 3), "sampling_loc shape mismatch")
+    _require(tuple(attn_weight.shape) == (N, Lq, M, L, P), "attn_weight shape mismatch")
+    step = min(N, int(im2col_step))
+    _require(step > 0 and N % step == 0,
+             "batch(%d) must divide im2col_step(%d)" % (N, step))      # .cu:52
+    _require(value.dtype in _DT, "unsupported value dtype %s" % value.dtype)
+    return N, S, M, C, L, Lq, P
+
+
+def _coerce_loc(value, sampling_loc, attn_weight):
+    # bf16/f16 value may come with fp32 locations (what autocast produces) or
+    # with same-dtype locations; anything else is converted to fp32 / value dtype.
+    half = value.dtype in (torch.bfloat16, torch.float16)
+    if sampling_loc.dtype != attn_weight.dtype or not (
+            sampling_loc.dtype == value.dtype or (half and sampling_loc.dtype == torch.float32)):
+        want = torch.float32 if half else value.dtype
+        sampling_loc = sampling_loc.to(want).contiguous()
+        attn_weight = attn_weight.to(want).contiguous()
+    return sampling_loc, attn_weight
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """-> Tensor (N, Lq, M*C); replaces ops/src/ms_deform_attn.h:20-39."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    N, S, M, C, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc,
+                                 attn_weight, im2col_step)
+    sampling_loc, attn_weight = _coerce_loc(value, sampling_loc, attn_weight)
+    out = torch.empty((N, Lq, M * C), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _native.lib.transoar_msda3d_forward(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+            N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype], flags, stream)
+    _native.check(rc, "transoar_msda3d_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]; replaces
+    ops/src/ms_deform_attn.h:41-61."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    N, S, M, C, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc,
+                                 attn_weight, im2col_step)
+    _require(tuple(grad_output.shape) == (N, Lq, M * C) and grad_output.dtype == value.dtype,
+             "grad_output must be (N, Lq, M*C) with value's dtype")
+    loc_in_dtype, attn_in_dtype = sampling_loc.dtype, attn_weight.dtype
+    sampling_loc, attn_weight = _coerce_loc(value, sampling_loc, attn_weight)
+    half = value.dtype in (torch.bfloat16, torch.float16)
+    # scatter target; fp32 accumulator for 16-bit storage (see the header)
+    grad_value = torch.zeros(value.shape, dtype=torch.float32 if half else value.dtype,
+                             device=value.device)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _native.lib.transoar_msda3d_backward(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+            N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype], flags, stream)
+    _native.check(rc, "transoar_msda3d_backward")
+    if half:
+        grad_value = grad_value.to(value.dtype)
+    return [grad_value, grad_loc.to(loc_in_dtype), grad_attn.to(attn_in_dtype)]
