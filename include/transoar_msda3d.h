@@ -37,6 +37,7 @@
 #ifndef TRANSOAR_MSDA3D_H
 #define TRANSOAR_MSDA3D_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -59,7 +60,8 @@ enum {
   TRANSOAR_ERR_DIM = -2,         /* a dimension is <= 0 or too large      */
   TRANSOAR_ERR_DTYPE = -3,       /* unsupported dtype combination         */
   TRANSOAR_ERR_ALIGN = -4,       /* a buffer is not 16-byte aligned       */
-  TRANSOAR_ERR_LEVELS = -5       /* L > TRANSOAR_MSDA3D_MAX_LEVELS        */
+  TRANSOAR_ERR_LEVELS = -5,      /* L > TRANSOAR_MSDA3D_MAX_LEVELS        */
+  TRANSOAR_ERR_WORKSPACE = -6    /* workspace smaller than required       */
 };
 
 #define TRANSOAR_MSDA3D_MAX_LEVELS 8
@@ -87,14 +89,16 @@ int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
                             unsigned flags, void* hip_stream);
 
 /*
- * Backward.  Writes grad_sampling_loc (shape of sampling_loc, loc_dtype) and
- * grad_attn_weight (shape of attn_weight, loc_dtype) completely, and
- * ACCUMULATES into grad_value with atomics: the caller must zero grad_value
- * first (the reference does the same with at::zeros_like, .cu:122).
+ * Backward.  Writes grad_value (shape and dtype of value), grad_sampling_loc
+ * and grad_attn_weight (shapes of sampling_loc / attn_weight, loc_dtype)
+ * completely; none of them needs to be initialised (the reference zero-fills
+ * all three with at::zeros_like, .cu:122-124, and scatters with atomicAdd).
  *
- * grad_value dtype: equal to value_dtype for F32/F64; for BF16/F16 value the
- * accumulator buffer is F32 (N*S*M*C floats) -- 16-bit atomics would lose the
- * sum -- and the caller casts afterwards.
+ * `workspace` is a 16-byte aligned device scratch buffer of at least
+ * transoar_msda3d_backward_workspace_bytes(...) bytes (same dims, dtypes and
+ * flags); it holds the sampling points sorted by cell, from which grad_value
+ * is gathered without atomics.  Its contents are dead after the call's
+ * kernels have run on `stream`.
  * Replaces ms_deform_attn_backward (ops/src/ms_deform_attn.h:41-61).
  */
 int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
@@ -102,9 +106,17 @@ int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
                              const void* sampling_loc, const void* attn_weight,
                              const void* grad_out, void* grad_value,
                              void* grad_sampling_loc, void* grad_attn_weight,
+                             void* workspace, size_t workspace_bytes,
                              int N, int S, int M, int C, int L, int Lq, int P,
                              int value_dtype, int loc_dtype, unsigned flags,
                              void* hip_stream);
+
+/* Scratch bytes transoar_msda3d_backward needs (0 if the arguments are
+ * invalid).  Pure host arithmetic. */
+size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C,
+                                                int L, int Lq, int P,
+                                                int value_dtype, int loc_dtype,
+                                                unsigned flags);
 
 /* Human-readable text for a return code of the functions above. */
 const char* transoar_msda3d_strerror(int code);

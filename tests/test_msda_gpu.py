@@ -177,7 +177,7 @@ def test_ragged_and_degenerate_shapes(MSDA):
         ro = c_oracle.forward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy())
         rgv, rgl, rga = c_oracle.backward(v.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), a.numpy(), go.numpy())
         for got, ref in ((out, ro), (gv, rgv), (gl, rgl), (ga, rga)):
-            assert relerr(got, torch.from_numpy(ref)) <= 1e-5, (N, M, C, Lq, levels, P)
+            assert relerr(got, torch.from_numpy(ref)) <= 1e-4, (N, M, C, Lq, levels, P)
 
 
 def test_all_points_outside_gives_zero(MSDA):

@@ -1,7 +1,8 @@
 """In-tree hipcc build of the gfx950 shared libraries (no torch cpp_extension,
 no hipify: the sources are HIP written for CDNA4 and compiled as-is).
 
-    python -m transoar_amd._build            # build everything that is stale
+    python transoar_amd/_build.py [--force]   # run by PATH: importing the package
+                                              # would load the (possibly stale) .so
 """
 import os
 import subprocess

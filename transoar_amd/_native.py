@@ -12,7 +12,7 @@ _LIB_NAME = "libtransoar_msda3d.so"
 
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FORCE_GENERIC = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NativeLibraryError(ImportError):
@@ -24,7 +24,7 @@ def _load():
     if not os.path.exists(path):
         raise NativeLibraryError(
             "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `python -m transoar_amd._build`) in the repository root; there is no "
+            "(or `python transoar_amd/_build.py`) in the repository root; there is no "
             "fallback implementation." % path)
     lib = ctypes.CDLL(path)
     c_int, c_void_p, c_uint = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint
@@ -32,7 +32,10 @@ def _load():
         lib.transoar_msda3d_forward.restype = c_int
         lib.transoar_msda3d_forward.argtypes = [c_void_p] * 6 + [c_int] * 9 + [c_uint, c_void_p]
         lib.transoar_msda3d_backward.restype = c_int
-        lib.transoar_msda3d_backward.argtypes = [c_void_p] * 9 + [c_int] * 9 + [c_uint, c_void_p]
+        lib.transoar_msda3d_backward.argtypes = ([c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 9 +
+                                                 [c_uint, c_void_p])
+        lib.transoar_msda3d_backward_workspace_bytes.restype = ctypes.c_size_t
+        lib.transoar_msda3d_backward_workspace_bytes.argtypes = [c_int] * 9 + [c_uint]
         lib.transoar_msda3d_strerror.restype = ctypes.c_char_p
         lib.transoar_msda3d_strerror.argtypes = [c_int]
         lib.transoar_msda3d_abi_version.restype = c_int

@@ -1,381 +1,22 @@
-// MSDeformAttn-3D for MI355X (gfx950): forward gather and backward
-// gather+scatter, plus the C ABI of include/transoar_msda3d.h.
+// MSDeformAttn-3D for MI355X (gfx950): the C ABI of include/transoar_msda3d.h
+// and the host-side dispatch onto the kernels in
+//   msda3d_gather.hpp   forward + grad_loc/grad_attn (query-stationary gathers)
+//   msda3d_scatter.hpp  grad_value (cell sort + voxel-stationary pull, no atomics)
+//   msda3d_generic.hpp  any-C / fp64 correctness kernels
 //
-// What it computes is fixed by the reference (semantics: SURVEY.md appendix A;
-// ops/src/cuda/ms_deform_im2col_cuda.cuh:31-114, 116-241, 370-439).  How it is
-// computed is not the reference's: the reference gives every output channel
-// its own thread and issues 128 strided 4-byte loads per thread; here
-//
-//   * one wave64 owns one (batch, query, head) item;
-//   * the item's 3*L*P location floats and L*P attention weights are read
-//     once, coalesced, and turned into wave-uniform scalars with v_readlane;
-//   * lanes are laid out  corner-group x channel-vector: each lane moves 16 B
-//     (global_load_dwordx4), LPV = C*elt/16 lanes cover one voxel's head
-//     slice, so one load instruction fetches 64/LPV of the 8 trilinear corners
-//     (all 8 for bf16 C=64, 4 for fp32 C=64) as full 128/256-byte rows;
-//   * the sum over L*P points and corners stays in registers; one xor-shuffle
-//     tree over the corner groups finishes the item;
-//   * backward: the per-point channel reductions for grad_attn / grad_loc are
-//     not done point by point through LDS trees + __syncthreads (reference
-//     :551-661) but kept as 4 partials per point in registers and finished for
-//     16 points at once with a 63-step wave sum-transpose, after which lane r
-//     owns output r and the 48 grad_loc + 16 grad_attn floats of the item go
-//     out as one contiguous burst;
-//   * grad_value is scattered with hardware fp32/fp64 atomics
-//     (global_atomic_add_f32/f64), fp32 accumulation for 16-bit storage.
-//
-// Bound: HBM/L2 bandwidth (18 flop per gathered byte); no MFMA in here.
+// What is computed is fixed by the reference (semantics: SURVEY.md appendix A;
+// ops/src/cuda/ms_deform_im2col_cuda.cuh:31-114, 116-241, 370-439).  How is
+// not: see the kernel headers.  Bound: HBM/L2 bandwidth (18 flop per gathered
+// byte); no MFMA in here.
+#include <algorithm>
+
 #include "../../include/transoar_msda3d.h"
 #include "msda3d_common.hpp"
+#include "msda3d_gather.hpp"
+#include "msda3d_generic.hpp"
+#include "msda3d_scatter.hpp"
 
 namespace transoar {
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kChunk = 16;  // points handled per location-load round
-
-template <typename A> struct PointGeom {
-  A ld, lh, lw;      // fractional parts
-  int d0, h0, w0;    // low corner
-};
-
-// ---------------------------------------------------------------------------
-// forward, vectorised
-// ---------------------------------------------------------------------------
-template <typename VT, typename LT, int LOG2_LPV>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_vec(
-    const VT* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
-    const LT* __restrict__ attn, VT* __restrict__ out, int S, int M, int C,
-    int L, int Lq, int P, long n_items, long n_blocks) {
-  using A = typename Elem<VT>::acc;
-  constexpr int VEC = Elem<VT>::VEC;
-  constexpr int LPV = 1 << LOG2_LPV;   // lanes per voxel row
-  constexpr int CPI = 64 / LPV;        // corners per load instruction
-  constexpr int NI = 8 / CPI;          // load instructions per point
-  static_assert(CPI >= 1 && CPI <= 8, "lane layout");
-
-  const long blk = xcd_contiguous_block(blockIdx.x, n_blocks);
-  if (blk < 0) return;
-  const int lane = threadIdx.x & 63;
-  const long item = __builtin_amdgcn_readfirstlane(
-      static_cast<int>(blk * kWavesPerBlock + (threadIdx.x >> 6)));
-  if (item >= n_items) return;
-  const int m = static_cast<int>(item % M);
-  const long b = (item / M) / Lq;
-  const int cv = lane & (LPV - 1);
-  const int cg = lane >> LOG2_LPV;
-  const long row_stride = static_cast<long>(M) * C;
-  const int LP = L * P;
-
-  const VT* vhead = value + (b * S * M + m) * C + cv * VEC;
-  const LT* loc_i = loc + item * LP * 3;
-  const LT* attn_i = attn + item * LP;
-
-  A acc[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) acc[e] = A(0);
-
-  int l = 0, p = 0;
-  int D = static_cast<int>(shapes[0]), H = static_cast<int>(shapes[1]),
-      W = static_cast<int>(shapes[2]);
-  long start = lsi[0];
-
-  for (int j0 = 0; j0 < LP; j0 += kChunk) {
-    const int nj = min(kChunk, LP - j0);
-    const A lv = lane < 3 * nj ? static_cast<A>(Elem<LT>::ld(loc_i + 3 * j0 + lane)) : A(0);
-    const A av = lane < nj ? static_cast<A>(Elem<LT>::ld(attn_i + j0 + lane)) : A(0);
-    for (int jj = 0; jj < nj; ++jj) {
-      const A x = bcast(lv, 3 * jj), y = bcast(lv, 3 * jj + 1), z = bcast(lv, 3 * jj + 2);
-      const A a = bcast(av, jj);
-      const A w_im = pixel_coord(x, W), h_im = pixel_coord(y, H), d_im = pixel_coord(z, D);
-      if (d_im > A(-1) && h_im > A(-1) && w_im > A(-1) && d_im < D && h_im < H && w_im < W) {
-        const A fd = floor(d_im), fh = floor(h_im), fw = floor(w_im);
-        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
-        const A ld = d_im - fd, lh = h_im - fh, lw = w_im - fw;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int k = i * CPI + cg;  // corner: bit2 = d, bit1 = h, bit0 = w
-          const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
-          const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
-          const A wt = (dd ? ld : A(1) - ld) * (dh ? lh : A(1) - lh) * (dw ? lw : A(1) - lw) * a;
-          if (static_cast<unsigned>(d) < static_cast<unsigned>(D) &&
-              static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
-              static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
-            const long r = start + (static_cast<long>(d) * H + h) * W + w;
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(vhead + r * row_stride);
-            A v[VEC];
-            Elem<VT>::unpack(raw, v);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += wt * v[e];
-          }
-        }
-      }
-      if (++p == P) {
-        p = 0;
-        if (++l < L) {
-          D = static_cast<int>(shapes[3 * l]);
-          H = static_cast<int>(shapes[3 * l + 1]);
-          W = static_cast<int>(shapes[3 * l + 2]);
-          start = lsi[l];
-        }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int mask = LPV; mask < 64; mask <<= 1) {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] += xor_lanes(acc[e], mask);
-  }
-  if (cg == 0)
-    *reinterpret_cast<u32x4*>(out + item * C + cv * VEC) = Elem<VT>::pack(acc);
-}
-
-// ---------------------------------------------------------------------------
-// backward, vectorised
-// ---------------------------------------------------------------------------
-template <typename VT, typename LT, int LOG2_LPV>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_vec(
-    const VT* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
-    const LT* __restrict__ attn, const VT* __restrict__ grad_out,
-    typename Elem<VT>::acc* __restrict__ grad_value, LT* __restrict__ grad_loc,
-    LT* __restrict__ grad_attn, int S, int M, int C, int L, int Lq, int P,
-    long n_items, long n_blocks) {
-  using A = typename Elem<VT>::acc;
-  constexpr int VEC = Elem<VT>::VEC;
-  constexpr int LPV = 1 << LOG2_LPV;
-  constexpr int CPI = 64 / LPV;
-  constexpr int NI = 8 / CPI;
-
-  const long blk = xcd_contiguous_block(blockIdx.x, n_blocks);
-  if (blk < 0) return;
-  const int lane = threadIdx.x & 63;
-  const long item = __builtin_amdgcn_readfirstlane(
-      static_cast<int>(blk * kWavesPerBlock + (threadIdx.x >> 6)));
-  if (item >= n_items) return;
-  const int m = static_cast<int>(item % M);
-  const long b = (item / M) / Lq;
-  const int cv = lane & (LPV - 1);
-  const int cg = lane >> LOG2_LPV;
-  const long row_stride = static_cast<long>(M) * C;
-  const int LP = L * P;
-
-  const long head_off = (b * S * M + m) * C + cv * VEC;
-  const VT* vhead = value + head_off;
-  A* gvhead = grad_value + head_off;
-  const LT* loc_i = loc + item * LP * 3;
-  const LT* attn_i = attn + item * LP;
-
-  A g[VEC];
-  Elem<VT>::unpack(*reinterpret_cast<const u32x4*>(grad_out + item * C + cv * VEC), g);
-
-  int l = 0, p = 0;
-  int D = static_cast<int>(shapes[0]), H = static_cast<int>(shapes[1]),
-      W = static_cast<int>(shapes[2]);
-  long start = lsi[0];
-
-  for (int j0 = 0; j0 < LP; j0 += kChunk) {
-    const int nj = min(kChunk, LP - j0);
-    const A lv = lane < 3 * nj ? static_cast<A>(Elem<LT>::ld(loc_i + 3 * j0 + lane)) : A(0);
-    const A av = lane < nj ? static_cast<A>(Elem<LT>::ld(attn_i + j0 + lane)) : A(0);
-    // part[4*jj + {0,1,2,3}] = this lane's share of {grad_attn, grad_x, grad_y, grad_z}
-    A part[4 * kChunk];
-#pragma unroll
-    for (int i = 0; i < 4 * kChunk; ++i) part[i] = A(0);
-
-#pragma unroll
-    for (int jj = 0; jj < kChunk; ++jj) {
-      if (jj < nj) {
-        const A x = bcast(lv, 3 * jj), y = bcast(lv, 3 * jj + 1), z = bcast(lv, 3 * jj + 2);
-        const A a = bcast(av, jj);
-        const A w_im = pixel_coord(x, W), h_im = pixel_coord(y, H), d_im = pixel_coord(z, D);
-        if (d_im > A(-1) && h_im > A(-1) && w_im > A(-1) && d_im < D && h_im < H && w_im < W) {
-          const A fd = floor(d_im), fh = floor(h_im), fw = floor(w_im);
-          const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
-          const A ld = d_im - fd, lh = h_im - fh, lw = w_im - fw;
-          // grad_loc = size * a * sum_c g_c * d(sample_c)/d(coord)   (.cuh:238-240)
-          const A cw = a * W, ch = a * H, cd = a * D;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            const int k = i * CPI + cg;
-            const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
-            const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
-            if (static_cast<unsigned>(d) < static_cast<unsigned>(D) &&
-                static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
-                static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
-              const A wd = dd ? ld : A(1) - ld, wh = dh ? lh : A(1) - lh, ww = dw ? lw : A(1) - lw;
-              const long r = start + (static_cast<long>(d) * H + h) * W + w;
-              A v[VEC];
-              Elem<VT>::unpack(*reinterpret_cast<const u32x4*>(vhead + r * row_stride), v);
-              const A wt = wd * wh * ww;
-              const A wta = wt * a;
-              A dot = A(0);
-              A* gv = gvhead + r * row_stride;
-#pragma unroll
-              for (int e = 0; e < VEC; ++e) {
-                dot += g[e] * v[e];
-                atomic_accum(gv + e, wta * g[e]);
-              }
-              part[4 * jj + 0] += wt * dot;
-              part[4 * jj + 1] += (dw ? cw : -cw) * (wd * wh) * dot;
-              part[4 * jj + 2] += (dh ? ch : -ch) * (wd * ww) * dot;
-              part[4 * jj + 3] += (dd ? cd : -cd) * (wh * ww) * dot;
-            }
-          }
-        }
-        if (++p == P) {
-          p = 0;
-          if (++l < L) {
-            D = static_cast<int>(shapes[3 * l]);
-            H = static_cast<int>(shapes[3 * l + 1]);
-            W = static_cast<int>(shapes[3 * l + 2]);
-            start = lsi[l];
-          }
-        }
-      }
-    }
-
-    const A tot = sum_transpose64(part, lane);
-    const int jj = lane >> 2, comp = lane & 3;
-    if (jj < nj) {
-      const long j = item * LP + j0 + jj;
-      if (comp == 0)
-        Elem<LT>::st(grad_attn + j, tot);
-      else
-        Elem<LT>::st(grad_loc + 3 * j + (comp - 1), tot);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// generic kernels: any C, any dtype.  One wave per item, lanes stride over the
-// channels.  Used for the reference's odd gradcheck channel counts
-// (ops/test.py:122) and whenever C*elt is not 128/256/512 bytes.
-// ---------------------------------------------------------------------------
-template <typename VT, typename LT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_generic(
-    const VT* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
-    const LT* __restrict__ attn, VT* __restrict__ out, int S, int M, int C,
-    int L, int Lq, int P, long n_items) {
-  using A = typename Elem<VT>::acc;
-  const int lane = threadIdx.x & 63;
-  const long item = static_cast<long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int m = static_cast<int>(item % M);
-  const long b = (item / M) / Lq;
-  const long row_stride = static_cast<long>(M) * C;
-  const VT* vhead = value + (b * S * M + m) * C;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + lane;
-    A acc = A(0);
-    for (int l = 0; l < L; ++l) {
-      const int D = static_cast<int>(shapes[3 * l]), H = static_cast<int>(shapes[3 * l + 1]),
-                W = static_cast<int>(shapes[3 * l + 2]);
-      const long start = lsi[l];
-      for (int p = 0; p < P; ++p) {
-        const long j = (item * L + l) * P + p;
-        const A a = static_cast<A>(Elem<LT>::ld(attn + j));
-        const A w_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j)), W);
-        const A h_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 1)), H);
-        const A d_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 2)), D);
-        if (!(d_im > A(-1) && h_im > A(-1) && w_im > A(-1) && d_im < D && h_im < H && w_im < W))
-          continue;
-        const A fd = floor(d_im), fh = floor(h_im), fw = floor(w_im);
-        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
-        const A ld = d_im - fd, lh = h_im - fh, lw = w_im - fw;
-        A val = A(0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
-          const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
-          if (c < C && static_cast<unsigned>(d) < static_cast<unsigned>(D) &&
-              static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
-              static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
-            const long r = start + (static_cast<long>(d) * H + h) * W + w;
-            const A wt = (dd ? ld : A(1) - ld) * (dh ? lh : A(1) - lh) * (dw ? lw : A(1) - lw);
-            val += wt * static_cast<A>(Elem<VT>::ld(vhead + r * row_stride + c));
-          }
-        }
-        acc += val * a;
-      }
-    }
-    if (c < C) Elem<VT>::st(out + item * C + c, acc);
-  }
-}
-
-template <typename VT, typename LT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_generic(
-    const VT* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
-    const LT* __restrict__ attn, const VT* __restrict__ grad_out,
-    typename Elem<VT>::acc* __restrict__ grad_value, LT* __restrict__ grad_loc,
-    LT* __restrict__ grad_attn, int S, int M, int C, int L, int Lq, int P,
-    long n_items) {
-  using A = typename Elem<VT>::acc;
-  const int lane = threadIdx.x & 63;
-  const long item = static_cast<long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int m = static_cast<int>(item % M);
-  const long b = (item / M) / Lq;
-  const long row_stride = static_cast<long>(M) * C;
-  const long head_off = (b * S * M + m) * C;
-  const VT* vhead = value + head_off;
-  A* gvhead = grad_value + head_off;
-  for (int l = 0; l < L; ++l) {
-    const int D = static_cast<int>(shapes[3 * l]), H = static_cast<int>(shapes[3 * l + 1]),
-              W = static_cast<int>(shapes[3 * l + 2]);
-    const long start = lsi[l];
-    for (int p = 0; p < P; ++p) {
-      const long j = (item * L + l) * P + p;
-      const A a = static_cast<A>(Elem<LT>::ld(attn + j));
-      const A w_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j)), W);
-      const A h_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 1)), H);
-      const A d_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 2)), D);
-      A pa = A(0), pw = A(0), ph = A(0), pd = A(0);
-      if (d_im > A(-1) && h_im > A(-1) && w_im > A(-1) && d_im < D && h_im < H && w_im < W) {
-        const A fd = floor(d_im), fh = floor(h_im), fw = floor(w_im);
-        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
-        const A ld = d_im - fd, lh = h_im - fh, lw = w_im - fw;
-        for (int c = lane; c < C; c += 64) {
-          const A top = static_cast<A>(Elem<VT>::ld(grad_out + item * C + c));
-          const A top_a = top * a;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
-            const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
-            if (static_cast<unsigned>(d) < static_cast<unsigned>(D) &&
-                static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
-                static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
-              const A wd = dd ? ld : A(1) - ld, wh = dh ? lh : A(1) - lh, ww = dw ? lw : A(1) - lw;
-              const long r = start + (static_cast<long>(d) * H + h) * W + w;
-              const A v = static_cast<A>(Elem<VT>::ld(vhead + r * row_stride + c));
-              atomic_accum(gvhead + r * row_stride + c, wd * wh * ww * top_a);
-              pa += wd * wh * ww * v * top;
-              pw += (dw ? A(1) : A(-1)) * wd * wh * v * top_a;
-              ph += (dh ? A(1) : A(-1)) * wd * ww * v * top_a;
-              pd += (dd ? A(1) : A(-1)) * wh * ww * v * top_a;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int mask = 1; mask < 64; mask <<= 1) {
-        pa += xor_lanes(pa, mask);
-        pw += xor_lanes(pw, mask);
-        ph += xor_lanes(ph, mask);
-        pd += xor_lanes(pd, mask);
-      }
-      if (lane == 0) {
-        Elem<LT>::st(grad_attn + j, pa);
-        Elem<LT>::st(grad_loc + 3 * j, pw * W);
-        Elem<LT>::st(grad_loc + 3 * j + 1, ph * H);
-        Elem<LT>::st(grad_loc + 3 * j + 2, pd * D);
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // host dispatch
@@ -390,13 +31,47 @@ static inline int lpv_log2(int C, int elt) {
   return -1;
 }
 
+static inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
+
+// Can the vector kernels run this problem?  (32-bit byte offsets into value,
+// 32-bit bin / point indices.)
+static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
+  if (flags & TRANSOAR_MSDA3D_FORCE_GENERIC) return -1;
+  const long value_bytes = static_cast<long>(d.N) * d.S * d.M * d.C * elt;
+  const long n_points = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
+  const long n_bins = static_cast<long>(d.N) * d.M * 8 * d.S;
+  if (value_bytes >= 0xfffffff0L || n_points >= (1L << 31) - 1 || n_bins >= (1L << 31) - 1) return -1;
+  return lpv_log2(d.C, elt);
+}
+
+struct BwdWorkspace {
+  size_t count, tile_sums, rank, rec_item, recs, total;
+  long n_bins, n_points, n_scan, n_tiles;
+};
+
+static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
+  BwdWorkspace w;
+  w.n_points = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
+  w.n_bins = static_cast<long>(d.N) * d.M * 8 * d.S;   // (D+1)(H+1)(W+1) <= 8*D*H*W
+  w.n_scan = w.n_bins + 1;
+  w.n_tiles = (w.n_scan + kScanTile - 1) / kScanTile;
+  size_t off = 0;
+  w.count = off;     off += align16(sizeof(int) * w.n_scan);
+  w.tile_sums = off; off += align16(sizeof(int) * w.n_tiles);
+  w.rank = off;      off += align16(sizeof(int) * w.n_points);
+  w.rec_item = off;  off += align16(sizeof(int) * w.n_points);
+  w.recs = off;      off += align16(4 * acc_size * w.n_points);
+  w.total = off;
+  return w;
+}
+
 template <typename VT, typename LT>
 static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, void* out, const Dims& d,
                       unsigned flags, hipStream_t st) {
   const long n_items = static_cast<long>(d.N) * d.Lq * d.M;
   const long n_blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int lg = (flags & TRANSOAR_MSDA3D_FORCE_GENERIC) ? -1 : lpv_log2(d.C, sizeof(VT));
+  const int lg = vec_lpv(d, sizeof(VT), flags);
   const dim3 block(64 * kWavesPerBlock);
   auto v = static_cast<const VT*>(value);
   auto lo = static_cast<const LT*>(loc);
@@ -407,9 +82,10 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
                        lo, at, o, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
   } else {
     const dim3 grid(((n_blocks + 7) / 8) * 8);
+    const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
 #define TRANSOAR_FWD(LG)                                                                      \
   hipLaunchKernelGGL((msda3d_fwd_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, at, \
-                     o, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items, n_blocks)
+                     o, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_items, n_blocks)
     if (lg == 3) TRANSOAR_FWD(3);
     else if (lg == 4) TRANSOAR_FWD(4);
     else TRANSOAR_FWD(5);
@@ -419,35 +95,96 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
 }
 
 template <typename VT, typename LT>
+static size_t bwd_workspace_bytes(const Dims& d, unsigned flags) {
+  using A = typename Elem<VT>::acc;
+  if (vec_lpv(d, sizeof(VT), flags) >= 0) return bwd_workspace(d, sizeof(A)).total;
+  // generic path: fp32 accumulator for 16-bit storage
+  return sizeof(VT) == 2 ? align16(sizeof(float) * static_cast<size_t>(d.N) * d.S * d.M * d.C) : 0;
+}
+
+#define TRANSOAR_CHECK_HIP(expr)                         \
+  do {                                                   \
+    const hipError_t e_ = (expr);                        \
+    if (e_ != hipSuccess) return static_cast<int>(e_);   \
+  } while (0)
+
+template <typename VT, typename LT>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* grad_value,
-                      void* grad_loc, void* grad_attn, const Dims& d, unsigned flags,
-                      hipStream_t st) {
+                      void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes,
+                      const Dims& d, unsigned flags, hipStream_t st) {
   using A = typename Elem<VT>::acc;
+  if (workspace_bytes < bwd_workspace_bytes<VT, LT>(d, flags)) return TRANSOAR_ERR_WORKSPACE;
   const long n_items = static_cast<long>(d.N) * d.Lq * d.M;
   const long n_blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int lg = (flags & TRANSOAR_MSDA3D_FORCE_GENERIC) ? -1 : lpv_log2(d.C, sizeof(VT));
+  const int lg = vec_lpv(d, sizeof(VT), flags);
   const dim3 block(64 * kWavesPerBlock);
   auto v = static_cast<const VT*>(value);
   auto lo = static_cast<const LT*>(loc);
   auto at = static_cast<const LT*>(attn);
   auto go = static_cast<const VT*>(grad_out);
-  auto gv = static_cast<A*>(grad_value);
   auto gl = static_cast<LT*>(grad_loc);
   auto ga = static_cast<LT*>(grad_attn);
+  const size_t value_elems = static_cast<size_t>(d.N) * d.S * d.M * d.C;
+
   if (lg < 0) {
+    // scatter with fp atomics into a zeroed accumulator of type A
+    A* gv = sizeof(VT) == 2 ? static_cast<A*>(workspace) : static_cast<A*>(grad_value);
+    TRANSOAR_CHECK_HIP(hipMemsetAsync(gv, 0, sizeof(A) * value_elems, st));
     hipLaunchKernelGGL((msda3d_bwd_generic<VT, LT>), dim3(n_blocks), block, 0, st, v, shapes, lsi,
                        lo, at, go, gv, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
-  } else {
-    const dim3 grid(((n_blocks + 7) / 8) * 8);
-#define TRANSOAR_BWD(LG)                                                                      \
-  hipLaunchKernelGGL((msda3d_bwd_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, at, \
-                     go, gv, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items, n_blocks)
-    if (lg == 3) TRANSOAR_BWD(3);
-    else if (lg == 4) TRANSOAR_BWD(4);
-    else TRANSOAR_BWD(5);
-#undef TRANSOAR_BWD
+    if (sizeof(VT) == 2) {
+      const int cast_blocks = static_cast<int>(std::min<size_t>((value_elems + 255) / 256, 1 << 16));
+      hipLaunchKernelGGL((msda3d_cast_rows<VT>), dim3(cast_blocks), dim3(256), 0, st,
+                         reinterpret_cast<const float*>(gv), static_cast<VT*>(grad_value),
+                         static_cast<long>(value_elems));
+    }
+    return static_cast<int>(hipGetLastError());
   }
+
+  const dim3 grid(((n_blocks + 7) / 8) * 8);
+  const unsigned vbytes = static_cast<unsigned>(value_elems * sizeof(VT));
+  // 1. grad_loc / grad_attn
+#define TRANSOAR_BWDQ(LG)                                                                   \
+  hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
+                     at, go, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_items, n_blocks)
+  if (lg == 3) TRANSOAR_BWDQ(3);
+  else if (lg == 4) TRANSOAR_BWDQ(4);
+  else TRANSOAR_BWDQ(5);
+#undef TRANSOAR_BWDQ
+
+  // 2. sort the sampling points by cell
+  const BwdWorkspace w = bwd_workspace(d, sizeof(A));
+  char* ws = static_cast<char*>(workspace);
+  int* count = reinterpret_cast<int*>(ws + w.count);
+  int* tile_sums = reinterpret_cast<int*>(ws + w.tile_sums);
+  int* rank = reinterpret_cast<int*>(ws + w.rank);
+  int* rec_item = reinterpret_cast<int*>(ws + w.rec_item);
+  auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
+  TRANSOAR_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * w.n_scan, st));
+  const dim3 pgrid(static_cast<unsigned>((w.n_points + 255) / 256));
+  hipLaunchKernelGGL((msda3d_cell_count<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                     rank, d.M, d.L, d.Lq, d.P, w.n_points);
+  hipLaunchKernelGGL(msda3d_scan_tiles, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0,
+                     st, count, tile_sums, static_cast<int>(w.n_scan));
+  hipLaunchKernelGGL(msda3d_scan_tile_sums, dim3(1), dim3(kScanThreads), 0, st, tile_sums,
+                     static_cast<int>(w.n_tiles));
+  hipLaunchKernelGGL(msda3d_scan_add, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0, st,
+                     count, tile_sums, static_cast<int>(w.n_scan));
+  hipLaunchKernelGGL((msda3d_cell_fill<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                     rank, recs, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
+
+  // 3. grad_value rows
+  const long n_rows = static_cast<long>(d.N) * d.S * d.M;
+  const long r_blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  const dim3 rgrid(((r_blocks + 7) / 8) * 8);
+#define TRANSOAR_PULL(LG)                                                                        \
+  hipLaunchKernelGGL((msda3d_bwd_value_pull<VT, A, LG>), rgrid, block, 0, st, go, shapes, lsi, count, \
+                     recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks)
+  if (lg == 3) TRANSOAR_PULL(3);
+  else if (lg == 4) TRANSOAR_PULL(4);
+  else TRANSOAR_PULL(5);
+#undef TRANSOAR_PULL
   return static_cast<int>(hipGetLastError());
 }
 
@@ -502,7 +239,8 @@ extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatia
                                         const int64_t* level_start_index, const void* sampling_loc,
                                         const void* attn_weight, const void* grad_out,
                                         void* grad_value, void* grad_sampling_loc,
-                                        void* grad_attn_weight, int N, int S, int M, int C, int L,
+                                        void* grad_attn_weight, void* workspace,
+                                        size_t workspace_bytes, int N, int S, int M, int C, int L,
                                         int Lq, int P, int value_dtype, int loc_dtype,
                                         unsigned flags, void* hip_stream) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight ||
@@ -513,13 +251,22 @@ extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatia
   if (rc != TRANSOAR_OK) return rc;
   if (misaligned(value) || misaligned(sampling_loc) || misaligned(attn_weight) ||
       misaligned(grad_out) || misaligned(grad_value) || misaligned(grad_sampling_loc) ||
-      misaligned(grad_attn_weight))
+      misaligned(grad_attn_weight) || misaligned(workspace))
     return TRANSOAR_ERR_ALIGN;
+  if (!workspace && workspace_bytes != 0) return TRANSOAR_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   TRANSOAR_DISPATCH(value_dtype, loc_dtype,
                     (launch_bwd<VT, LT>(value, spatial_shapes, level_start_index, sampling_loc,
                                         attn_weight, grad_out, grad_value, grad_sampling_loc,
-                                        grad_attn_weight, d, flags, st)));
+                                        grad_attn_weight, workspace, workspace_bytes, d, flags, st)));
+}
+
+extern "C" size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C, int L, int Lq,
+                                                           int P, int value_dtype, int loc_dtype,
+                                                           unsigned flags) {
+  const Dims d{N, S, M, C, L, Lq, P};
+  if (check_common(d, value_dtype, loc_dtype) != TRANSOAR_OK) return 0;
+  TRANSOAR_DISPATCH(value_dtype, loc_dtype, (bwd_workspace_bytes<VT, LT>(d, flags)));
 }
 
 extern "C" const char* transoar_msda3d_strerror(int code) {
@@ -530,8 +277,9 @@ extern "C" const char* transoar_msda3d_strerror(int code) {
     case TRANSOAR_ERR_DTYPE: return "unsupported value/loc dtype combination";
     case TRANSOAR_ERR_ALIGN: return "a device buffer is not 16-byte aligned";
     case TRANSOAR_ERR_LEVELS: return "too many feature levels";
+    case TRANSOAR_ERR_WORKSPACE: return "workspace is smaller than transoar_msda3d_backward_workspace_bytes()";
     default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
   }
 }
 
-extern "C" int transoar_msda3d_abi_version(void) { return 1; }
+extern "C" int transoar_msda3d_abi_version(void) { return 2; }

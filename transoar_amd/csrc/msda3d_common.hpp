@@ -6,6 +6,9 @@
 
 namespace transoar {
 
+constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
+constexpr int kChunk = 16;          // sampling points per location-load round
+
 struct bf16_t { unsigned short bits; };
 struct f16_t { _Float16 v; };
 
@@ -91,26 +94,25 @@ template <> struct Elem<bf16_t> {
 template <> struct Elem<f16_t> {
   using acc = float;
   static constexpr int VEC = 8;
-  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  static __device__ __forceinline__ float h2f(unsigned int bits16) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(bits16)));
+  }
+  static __device__ __forceinline__ unsigned int f2h(float f) {
+    return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));
+  }
   static __device__ __forceinline__ float ld(const f16_t* p) { return static_cast<float>(p->v); }
   static __device__ __forceinline__ void st(f16_t* p, float v) { p->v = static_cast<_Float16>(v); }
   static __device__ __forceinline__ void unpack(const u32x4& r, float (&o)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const h2 h = __builtin_bit_cast(h2, r[i]);
-      o[2 * i] = static_cast<float>(h[0]);
-      o[2 * i + 1] = static_cast<float>(h[1]);
+      o[2 * i] = h2f(r[i] & 0xffffu);
+      o[2 * i + 1] = h2f(r[i] >> 16);
     }
   }
   static __device__ __forceinline__ u32x4 pack(const float (&o)[8]) {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h2 h;
-      h[0] = static_cast<_Float16>(o[2 * i]);
-      h[1] = static_cast<_Float16>(o[2 * i + 1]);
-      r[i] = __builtin_bit_cast(unsigned int, h);
-    }
+    for (int i = 0; i < 4; ++i) r[i] = f2h(o[2 * i]) | (f2h(o[2 * i + 1]) << 16);
     return r;
   }
 };
@@ -118,11 +120,16 @@ template <> struct Elem<f16_t> {
 // pixel coordinate of a normalised location: loc*size - 0.5 with the multiply
 // and the subtract rounded separately (no FMA contraction), so floor() picks
 // the same cell as the scalar oracle (oracle/msda3d_oracle_impl.h) bit for bit.
+// (HIP's __fmul_rn is a plain '*' and would still be contracted.)
 __device__ __forceinline__ float pixel_coord(float loc, int size) {
-  return __fsub_rn(__fmul_rn(loc, static_cast<float>(size)), 0.5f);
+#pragma clang fp contract(off)
+  const float t = loc * static_cast<float>(size);
+  return t - 0.5f;
 }
 __device__ __forceinline__ double pixel_coord(double loc, int size) {
-  return __dsub_rn(__dmul_rn(loc, static_cast<double>(size)), 0.5);
+#pragma clang fp contract(off)
+  const double t = loc * static_cast<double>(size);
+  return t - 0.5;
 }
 
 // wave-uniform broadcast of lane `src`'s value (src must be wave-uniform)
@@ -138,6 +145,10 @@ __device__ __forceinline__ double bcast(double v, int src) {
 
 __device__ __forceinline__ float xor_lanes(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double xor_lanes(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// value of lane `src` (per-lane index, ds_bpermute)
+__device__ __forceinline__ float xor_free_shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double xor_free_shfl(double v, int src) { return __shfl(v, src, 64); }
 
 // hardware fp atomics (no CAS loop): compiled with -munsafe-fp-atomics
 __device__ __forceinline__ void atomic_accum(float* p, float v) {

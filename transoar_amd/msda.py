@@ -107,20 +107,18 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
              "grad_output must be (N, Lq, M*C) with value's dtype")
     loc_in_dtype, attn_in_dtype = sampling_loc.dtype, attn_weight.dtype
     sampling_loc, attn_weight = _coerce_loc(value, sampling_loc, attn_weight)
-    half = value.dtype in (torch.bfloat16, torch.float16)
-    # scatter target; fp32 accumulator for 16-bit storage (see the header)
-    grad_value = torch.zeros(value.shape, dtype=torch.float32 if half else value.dtype,
-                             device=value.device)
+    grad_value = torch.empty_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
+    dims = (N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype])
+    ws_bytes = _native.lib.transoar_msda3d_backward_workspace_bytes(*dims, flags)
+    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _native.lib.transoar_msda3d_backward(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
             grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-            N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype], flags, stream)
+            workspace.data_ptr(), ws_bytes, *dims, flags, stream)
     _native.check(rc, "transoar_msda3d_backward")
-    if half:
-        grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_loc.to(loc_in_dtype), grad_attn.to(attn_in_dtype)]
