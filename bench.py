@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: training-step CT volumes/s of the Focused-Decoder model
+on synthetic 160x160x256 volumes (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + criterion + backward + gradient all-reduce + AdamW on one
+batch of 2 volumes per GPU (batch_size of config/attn_fpn_foc_dec_visceral.yaml),
+VISCERAL geometry, deformable-attention refinement ON
+(backbone.use_decoder_attn=True, use_cuda=True -> the gfx950 MSDeformAttn
+kernels; both are off in the shipped yaml), bf16 autocast, fp32
+master weights, random-init weights, synthetic data resident in HBM.
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
+  roofline      the MSDeformAttn kernel with the largest share of the timed
+                region: algorithmic bytes / its average launch
+                duration measured with HIP events on the launch stream
+  msda_kernels  the same for every MSDeformAttn kernel
+  cpu_baseline  one training step of the same model on the host CPU cores with
+                the oracle's torch core (kind "port"), batch 1, fp32
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
+    """Bytes one launch must move if every tensor is touched once."""
+    value, out = e * N * S * M * C, e * N * Lq * M * C
+    loc_attn = e_loc * N * Lq * M * L * P * 4
+    return {
+        "fwd": value + out + loc_attn,                       # SURVEY 8d B_fwd
+        "bwd_query": value + out + 2 * loc_attn,             # value, grad_out in; grad_loc/attn out
+        "pull": out + value + loc_attn,                      # grad_out in, grad_value out, point geometry
+        "cell_count": loc_attn, "cell_fill": loc_attn, "scan": 0,
+    }.get(kind, 0)
+
+
+def cpu_baseline_leg():
+    """Runs in a subprocess: one CPU training step (fp32, batch 1) of the same
+    model with the oracle's torch core, all host cores."""
+    import torch
+    from oracle.torch_ref import msda3d_core_torch
+    from transoar_amd import ms_deform_attn
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.train_step import TrainStep
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    ms_deform_attn.register_debug_core(msda3d_core_torch)
+    cfg = visceral_config(refine=True, use_cuda=False)
+    cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+    torch.manual_seed(0)
+    model = TransoarNet(cfg)
+    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.float32)
+    x = torch.rand(1, 1, *cfg["volume_shape"])
+    targets = synthetic_targets(1, cfg["num_classes"], seed=1)
+    t0 = time.perf_counter()
+    step(x, targets)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": 1.0 / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+                      "sample": "1 training step (fwd+loss+bwd+AdamW), batch 1, fp32, same model/geometry, "
+                                "oracle torch core (grid_sample) for MSDeformAttn, %.1f s" % dt}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
+    ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=420.0)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        return cpu_baseline_leg()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from transoar_amd import _native
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.matcher import DenseTargets
+    from transoar_amd.train_step import TrainStep
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+
+    cfg = visceral_config(refine=not args.no_refine, use_cuda=True)
+    cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+    torch.manual_seed(0)                       # identical replicas
+    model = TransoarNet(cfg).to(dev)
+    amp = torch.float32 if args.fp32 else torch.bfloat16
+    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp)
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand(args.batch, 1, *cfg["volume_shape"], device=dev, generator=g)
+    targets = DenseTargets.from_list(synthetic_targets(args.batch, cfg["num_classes"], seed=1 + rank, device=dev),
+                                     cfg["num_classes"], dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(x, targets)
+    barrier()
+    _native.profile_enable(True)
+    _native.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, _ = step(x, targets)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _native.profile_enable(False)
+    prof = _native.profile_read()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_value = float(total)
+    assert loss_value == loss_value, "loss is NaN"
+
+    if rank == 0:
+        global_batch = args.batch * world
+        # MSDeformAttn problem of the refine block at this geometry
+        shapes = [(40, 40, 64), (20, 20, 32), (10, 10, 16), (5, 5, 8)]
+        S = sum(d * h * w for d, h, w in shapes)
+        dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4)
+        kernels = {}
+        for kind, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            avg = ms / n
+            b = msda_algorithmic_bytes(kind, **dims)
+            kernels[kind] = {"launches_per_step": n / args.steps, "avg_ms": round(avg, 4),
+                             "algorithmic_MB": round(b / 1e6, 1),
+                             "achieved_GBps": round(b / avg / 1e6, 1) if b else None}
+        roofline = None
+        if kernels:
+            dom = max((k for k in kernels if kernels[k]["achieved_GBps"]),
+                      key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+            kd = kernels[dom]
+            roofline = {"kernel": "msda3d_" + dom, "bound": "hbm", "achieved": kd["achieved_GBps"],
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kd["achieved_GBps"] / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "avg_launch_ms": kd["avg_ms"], "algorithmic_MB": kd["algorithmic_MB"],
+                        "timing": "hipEvent pairs on the launch stream inside the timed region"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"],
+                                   capture_output=True, text=True, timeout=args.cpu_baseline_timeout,
+                                   env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+                cpu = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:    # report, never fake
+                cpu = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port",
+                       "sample": "cpu baseline leg failed: %r" % (e,)}
+        print(json.dumps({
+            "metric": "training-step CT volumes/s, 160x160x256 Focused-Decoder",
+            "value": round(global_batch * args.steps / elapsed, 4), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Focused Decoder, 160x160x256 (VISCERAL geometry), "
+                                   "batch 2 per GPU, bf16 autocast, refine %s" % ("off" if args.no_refine else
+                                                                                     "on (use_decoder_attn, use_cuda)"),
+                       "global_batch": global_batch, "per_gpu_batch": args.batch, "volume": list(cfg["volume_shape"]),
+                       "parallelism": "dp%d" % world, "weights": "random init", "optimizer": "AdamW fused",
+                       "params": sum(p.numel() for p in model.parameters())},
+            "loss": round(loss_value, 5),
+            "roofline": roofline, "msda_kernels": kernels, "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

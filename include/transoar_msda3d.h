@@ -118,6 +118,28 @@ size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C,
                                                 int value_dtype, int loc_dtype,
                                                 unsigned flags);
 
+/*
+ * Optional per-kernel timing (used by bench.py for the roofline figures).
+ * While enabled, every kernel the two entry points launch is bracketed by a
+ * HIP event pair recorded on the caller's stream.  transoar_msda3d_profile_read
+ * waits for the recorded pairs, adds their elapsed times per kernel kind into
+ * total_ms[TRANSOAR_PROF_KINDS] / launches[TRANSOAR_PROF_KINDS] (both
+ * overwritten) and forgets them.  Returns 0 or a hipError_t.
+ */
+enum {
+  TRANSOAR_PROF_FWD = 0,          /* msda3d_fwd_vec                     */
+  TRANSOAR_PROF_BWD_QUERY = 1,    /* msda3d_bwd_query_vec               */
+  TRANSOAR_PROF_CELL_COUNT = 2,   /* msda3d_cell_count                  */
+  TRANSOAR_PROF_SCAN = 3,         /* the three msda3d_scan_* launches   */
+  TRANSOAR_PROF_CELL_FILL = 4,    /* msda3d_cell_fill                   */
+  TRANSOAR_PROF_PULL = 5,         /* msda3d_bwd_value_pull              */
+  TRANSOAR_PROF_FWD_GENERIC = 6,
+  TRANSOAR_PROF_BWD_GENERIC = 7,
+  TRANSOAR_PROF_KINDS = 8
+};
+void transoar_msda3d_profile_enable(int on);
+int transoar_msda3d_profile_read(double* total_ms, long* launches);
+
 /* Human-readable text for a return code of the functions above. */
 const char* transoar_msda3d_strerror(int code);
 

@@ -82,3 +82,55 @@ def load_case(npz, prefix):
 
 def case_prefixes(npz):
     return sorted({k.split(".")[0] for k in npz.files})
+
+
+# ---------------------------------------------------------------------------
+# model-level fixtures: deterministic weights + analytic volume, so the golden
+# files only need to hold outputs
+# ---------------------------------------------------------------------------
+def fill_deterministic(module, gain=1.0):
+    """Overwrite every parameter of `module` with a closed-form pattern that
+    depends only on the parameter's position in state_dict order and its shape.
+    Used identically on the reference model (make_golden.py) and on ours."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            n = p.numel()
+            idx = torch.arange(n, dtype=torch.float64)
+            fan_in = p[0].numel() if p.dim() > 1 else 1
+            scale = gain * (1.0 / max(fan_in, 1)) ** 0.5 if p.dim() > 1 else 0.1
+            vals = scale * torch.sin(idx * (0.37 + 0.01 * (k % 7)) + 0.5 * k)
+            if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("norm3.weight") \
+                    or (p.dim() == 1 and ("_block.1.weight" in name or "_block.4.weight" in name)):
+                vals = 1.0 + 0.1 * vals          # norm gains around 1
+            p.copy_(vals.reshape(p.shape).to(p.dtype))
+
+
+def analytic_volume(shape, batch=1):
+    """x = 0.5 + 0.5 sin(.05 i) cos(.07 j) sin(.03 k + 1) (+0.1*b) on (b,1,i,j,k)."""
+    i = torch.arange(shape[0], dtype=torch.float32)[:, None, None]
+    j = torch.arange(shape[1], dtype=torch.float32)[None, :, None]
+    k = torch.arange(shape[2], dtype=torch.float32)[None, None, :]
+    vol = 0.5 + 0.5 * torch.sin(0.05 * i) * torch.cos(0.07 * j) * torch.sin(0.03 * k + 1.0)
+    return torch.stack([vol + 0.1 * b for b in range(batch)])[:, None]
+
+
+def small_backbone_config(refine, use_cuda=False, levels=("P2", "P3", "P4", "P5")):
+    return dict(
+        name="attn_fpn", use_encoder_attn=False, conv_kernels=[[3, 3, 3]] * 6,
+        strides=[[1, 1, 1]] + [[2, 2, 2]] * 5, in_channels=1, start_channels=4,
+        depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], window_size=[5, 5, 5], mlp_ratio=4, qkv_bias=True,
+        qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2, conv_merging=False,
+        use_decoder_attn=refine, fpn_channels=48, out_fmaps=["P2"], pos_encoding="sine",
+        feature_levels=list(levels), hidden_dim=48, dim_feedforward=64, dropout=0.1, nheads=6, layers=2,
+        n_points=4, use_cuda=use_cuda, use_seg_proxy_loss=False, fg_bg=True)
+
+
+def small_model_config(refine, use_cuda=False):
+    """Reduced-width VISCERAL-geometry model (the Focused Decoder's mask table
+    only admits 160x160x256, focused_decoder.py:99-117)."""
+    from transoar_amd.config import synthetic_bbox_properties, visceral_config
+    cfg = visceral_config(refine=refine, use_cuda=use_cuda)
+    cfg["backbone"] = small_backbone_config(refine, use_cuda)
+    cfg["neck"].update(hidden_dim=48, dim_feedforward=64)
+    cfg["bbox_properties"] = synthetic_bbox_properties(20, seed=0)
+    return cfg

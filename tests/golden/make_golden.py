@@ -14,7 +14,11 @@ The reference's own op test (ops/test.py:69-115) has no committed vectors and
 no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
 "Medium" shape with closed-form (RNG-free) inputs.
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py            # rewrites the op/module fixtures g1..g5
+    python tests/golden/make_golden.py --models   # additionally g6 (backbone), g7 (whole model)
+
+g6/g7 import the reference's full model, which needs two container-only shims
+(a stub ``timm.models.layers`` and ``Tensor.cuda = identity``).
 """
 import os
 import sys
@@ -198,12 +202,103 @@ def g5_refine_block():
     np.savez_compressed(os.path.join(HERE, "g5_refine_block.npz"), **store)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--models" not in sys.argv:
     g1_small()
     g2_edge()
     g3_medium()
     g4_module()
     g5_refine_block()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+# ---------------------------------------------------------------------------
+# model-level fixtures (appended): backbone (G6) and whole model + criterion (G7)
+# ---------------------------------------------------------------------------
+def _reference_model_imports():
+    import types
+    import torch.nn as nn
+
+    class _DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+    tl = types.ModuleType("timm.models.layers")
+    tl.trunc_normal_ = nn.init.trunc_normal_
+    tl.DropPath = _DropPath
+    sys.modules.update({"timm": types.ModuleType("timm"), "timm.models": types.ModuleType("timm.models"),
+                        "timm.models.layers": tl})
+    torch.Tensor.cuda = lambda self, *a, **k: self          # no GPU here
+    nn.Module.cuda = lambda self, *a, **k: self
+
+
+def g6_backbone():
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import analytic_volume, fill_deterministic, small_backbone_config
+    from transoar.models.backbones.attn_fpn import AttnFPN
+    x = analytic_volume((32, 32, 64))
+    store = {}
+    for tag, refine in (("plain", False), ("refine", True)):
+        net = AttnFPN(small_backbone_config(refine)).eval()
+        fill_deterministic(net)
+        out = net(x)
+        total = sum(o.sum() for o in out.values())
+        params = dict(net.named_parameters())
+        grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+        for k, v in out.items():
+            store["%s.%s" % (tag, k)] = v.detach().numpy()
+        store[tag + ".grad_names"] = np.array(list(params.keys()))
+        store[tag + ".grad_sums"] = np.array([0.0 if g is None else g.double().sum().item() for g in grads])
+        store[tag + ".grad_abs_sums"] = np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads])
+    np.savez_compressed(os.path.join(HERE, "g6_backbone.npz"), **store)
+
+
+def g7_whole_model():
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import analytic_volume, fill_deterministic, small_model_config
+    from transoar_amd.config import synthetic_targets
+    from transoar.models.transoarnet import TransoarNet
+    from transoar.models.build import build_criterion
+    store = {}
+    for tag, refine in (("plain", False), ("refine", True)):
+        cfg = small_model_config(refine)
+        net = TransoarNet(cfg).eval()
+        fill_deterministic(net)
+        crit = build_criterion(cfg)
+        x = analytic_volume((160, 160, 256), batch=2)
+        out = net(x)
+        targets = synthetic_targets(2, 20, seed=1)
+        losses = crit(out, targets, None, net._anchors)
+        coefs = cfg["loss_coefs"]
+        total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
+        params = dict(net.named_parameters())
+        grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+        store[tag + ".pred_logits"] = out["pred_logits"].detach().numpy()
+        store[tag + ".pred_boxes"] = out["pred_boxes"].detach().numpy()
+        for i, aux in enumerate(out["aux_outputs"]):
+            store["%s.aux%d_logits" % (tag, i)] = aux["pred_logits"].detach().numpy()
+            store["%s.aux%d_boxes" % (tag, i)] = aux["pred_boxes"].detach().numpy()
+        store[tag + ".loss_names"] = np.array(list(losses.keys()))
+        store[tag + ".loss_values"] = np.array([float(v) for v in losses.values()])
+        store[tag + ".total"] = np.float64(float(total))
+        store[tag + ".anchors"] = net._anchors.numpy()
+        store[tag + ".restrictions"] = net._restrictions.numpy()
+        store[tag + ".attn_mask_rowsum"] = net._neck.decoder.layers[0].attn_mask.sum(1).numpy()
+        store[tag + ".grad_names"] = np.array(list(params.keys()))
+        store[tag + ".grad_is_none"] = np.array([g is None for g in grads])
+        store[tag + ".grad_sums"] = np.array([0.0 if g is None else g.double().sum().item() for g in grads])
+        store[tag + ".grad_abs_sums"] = np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads])
+    np.savez_compressed(os.path.join(HERE, "g7_whole_model.npz"), **store)
+
+
+if __name__ == "__main__" and "--models" in sys.argv:
+    g6_backbone()
+    g7_whole_model()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

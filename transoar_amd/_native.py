@@ -12,7 +12,7 @@ _LIB_NAME = "libtransoar_msda3d.so"
 
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FORCE_GENERIC = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeLibraryError(ImportError):
@@ -36,6 +36,10 @@ def _load():
                                                  [c_uint, c_void_p])
         lib.transoar_msda3d_backward_workspace_bytes.restype = ctypes.c_size_t
         lib.transoar_msda3d_backward_workspace_bytes.argtypes = [c_int] * 9 + [c_uint]
+        lib.transoar_msda3d_profile_enable.restype = None
+        lib.transoar_msda3d_profile_enable.argtypes = [c_int]
+        lib.transoar_msda3d_profile_read.restype = c_int
+        lib.transoar_msda3d_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
         lib.transoar_msda3d_strerror.restype = ctypes.c_char_p
         lib.transoar_msda3d_strerror.argtypes = [c_int]
         lib.transoar_msda3d_abi_version.restype = c_int
@@ -56,3 +60,18 @@ def check(code, what):
     if code != 0:
         raise RuntimeError("%s failed: %s (code %d)" % (
             what, lib.transoar_msda3d_strerror(code).decode(), code))
+
+
+PROF_KINDS = ("fwd", "bwd_query", "cell_count", "scan", "cell_fill", "pull", "fwd_generic", "bwd_generic")
+
+
+def profile_enable(on):
+    lib.transoar_msda3d_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """-> {kind: (total_ms, launches)} for the kernels recorded since the last read."""
+    ms = (ctypes.c_double * len(PROF_KINDS))()
+    n = (ctypes.c_long * len(PROF_KINDS))()
+    check(lib.transoar_msda3d_profile_read(ms, n), "transoar_msda3d_profile_read")
+    return {k: (ms[i], n[i]) for i, k in enumerate(PROF_KINDS)}

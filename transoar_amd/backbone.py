@@ -1,0 +1,149 @@
+"""3-D conv FPN backbone (AttnFPN): six conv stages down, lateral / transposed
+conv / output convs up, optional deformable-attention refinement.
+
+Mirrors transoar/models/backbones/attn_fpn.py (AttnFPN :18-32, Decoder :34-145,
+Encoder :148-213) and EncoderCnnBlock (encoder_blocks.py:14-54): same config
+keys, same parameter names (``_encoder._stages.N._block.K``, ``_decoder._lateral
+/_up/_out/_refine``) so reference checkpoints load with strict=True.
+The Swin encoder (``use_encoder_attn``) is outside this build's scope
+ and raises.
+"""
+import torch
+from torch import nn
+
+from .position_encoding import PositionEmbeddingLearned3D, PositionEmbeddingSine3D
+from .refine_block import DecoderDefAttnBlock
+
+
+class EncoderCnnBlock(nn.Module):
+    """[Conv3d(k, stride, pad, no bias) -> InstanceNorm3d(affine) -> ReLU] x 2;
+    only the first conv strides."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=1, bias=False,
+                 affine=True, eps=1e-05):
+        super().__init__()
+        kernel_size, stride = tuple(kernel_size), tuple(stride)
+        self._block = nn.Sequential(
+            nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias),
+            nn.InstanceNorm3d(out_channels, affine=affine, eps=eps),
+            nn.ReLU(inplace=True),
+            nn.Conv3d(out_channels, out_channels, kernel_size, stride=1, padding=padding, bias=bias),
+            nn.InstanceNorm3d(out_channels, affine=affine, eps=eps),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):
+        return self._block(x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, config, debug=False):
+        super().__init__()
+        if config["use_encoder_attn"]:
+            raise NotImplementedError(
+                "use_encoder_attn=True (Swin stages, encoder_blocks.py:56-400) is out of scope of the "
+                "MI355X hot path build; see DESIGN.md")
+        self._debug = debug
+        self._stages = nn.ModuleList()
+        cin, cout = config["in_channels"], config["start_channels"]
+        for kernel, stride in zip(config["conv_kernels"], config["strides"]):
+            self._stages.append(EncoderCnnBlock(cin, cout, kernel, stride))
+            cin, cout = cout, cout * 2
+
+    def forward(self, x):
+        outputs = {}
+        for i, stage in enumerate(self._stages):
+            x = stage(x)
+            outputs["C%d" % i] = x
+        if self._debug:
+            print("AttnFPN encoder shapes:", {k: list(v.shape) for k, v in outputs.items()})
+            self._debug = False
+        return outputs
+
+
+class Decoder(nn.Module):
+    def __init__(self, config, debug=False):
+        super().__init__()
+        self._debug = debug
+        n_stages = len(config["conv_kernels"])
+        self._num_stages = n_stages
+        self._refine_fmaps = config["use_decoder_attn"]
+        self._refine_feature_levels = list(config["feature_levels"])
+        self._seg_proxy = config["use_seg_proxy_loss"]
+        fpn = int(config["fpn_channels"])
+        enc_channels = [config["start_channels"] * 2 ** s for s in range(n_stages)]
+
+        wanted = list(config["out_fmaps"]) + (list(config["feature_levels"]) if self._refine_fmaps else [])
+        required = {int(name[-1]) for name in wanted}
+        if self._seg_proxy:
+            required.add(0)
+        self._required_stages = sorted(required)
+        first = 0 if self._seg_proxy else self._required_stages[0]
+        self._first_stage = first
+
+        lateral_in = enc_channels[first:]
+        lateral_out = [min(c, fpn) for c in lateral_in]
+        self._lateral = nn.ModuleList(nn.Conv3d(i, o, kernel_size=1) for i, o in zip(lateral_in, lateral_out))
+        self._lateral_levels = len(self._lateral)
+
+        self._out = nn.ModuleList()
+        for n, stage in enumerate(self._required_stages):
+            cout = enc_channels[0] if (self._seg_proxy and n == 0) else fpn
+            self._out.append(nn.Conv3d(lateral_out[stage - first], cout, kernel_size=3, padding=1))
+
+        # top-down path, coarsest first
+        self._up = nn.ModuleList()
+        coarse_to_fine = lateral_out[::-1]
+        strides = [tuple(s) for s in config["strides"]][::-1]
+        for lvl in range(len(coarse_to_fine) - 1):
+            self._up.append(nn.ConvTranspose3d(coarse_to_fine[lvl], coarse_to_fine[lvl + 1],
+                                               kernel_size=strides[lvl], stride=strides[lvl]))
+
+        if self._refine_fmaps:
+            if config["pos_encoding"] == "sine":
+                self._pos_enc = PositionEmbeddingSine3D(channels=config["hidden_dim"])
+            elif config["pos_encoding"] == "learned":
+                self._pos_enc = PositionEmbeddingLearned3D(channels=config["hidden_dim"])
+            else:
+                raise ValueError("Please select a implemented pos. encoding.")
+            self._refine = DecoderDefAttnBlock(
+                d_model=config["hidden_dim"], nhead=config["nheads"], num_layers=config["layers"],
+                dim_feedforward=config["dim_feedforward"], dropout=config["dropout"],
+                feature_levels=config["feature_levels"], n_points=config["n_points"],
+                use_cuda=config["use_cuda"])
+
+    def forward(self, x):
+        feats = list(x.values())[-self._lateral_levels:]
+        laterals = [conv(f) for conv, f in zip(self._lateral, feats)]
+        # merged[s - first] = lateral_s + up(merged_{s+1})
+        merged = [None] * self._lateral_levels
+        carry = None
+        for k, lat in enumerate(reversed(laterals)):
+            cur = lat if carry is None else lat + carry
+            merged[self._lateral_levels - 1 - k] = cur
+            if k < self._lateral_levels - 1:
+                carry = self._up[k](cur)
+        outputs = {"P%d" % s: self._out[n](merged[s - self._first_stage])
+                   for n, s in enumerate(self._required_stages)}
+
+        if self._refine_fmaps:
+            fmaps = [outputs[name] for name in self._refine_feature_levels]
+            refined = self._refine(fmaps, [self._pos_enc(f) for f in fmaps])
+            outputs.update(zip(self._refine_feature_levels, refined))
+        if self._debug:
+            print("AttnFPN decoder shapes:", {k: list(v.shape) for k, v in outputs.items()})
+            self._debug = False
+        return outputs
+
+
+class AttnFPN(nn.Module):
+    def __init__(self, fpn_config, debug=False):
+        super().__init__()
+        self._encoder = Encoder(fpn_config, debug)
+        self._decoder = Decoder(fpn_config, debug)
+
+    def forward(self, src):
+        return self._decoder(self._encoder(src))
+
+    def init_weights(self):
+        pass

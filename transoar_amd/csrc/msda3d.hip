@@ -16,7 +16,45 @@
 #include "msda3d_generic.hpp"
 #include "msda3d_scatter.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace transoar {
+
+// ---- optional per-kernel timing with HIP events on the launch stream -------
+// bench.py turns this on for the timed region: every kernel launched by the
+// two entry points is bracketed by an event pair recorded on `stream`; the
+// pairs are resolved later by transoar_msda3d_profile_read (which synchronises
+// on them).  Off by default: zero cost.
+struct ProfPair { hipEvent_t beg, end; int kind; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfPair> g_prof_live;   // recorded, not yet read
+static std::vector<ProfPair> g_prof_free;   // reusable event pairs
+
+struct ProfScope {
+  hipStream_t st;
+  ProfPair pair;
+  bool on;
+  ProfScope(int kind, hipStream_t s) : st(s), on(false) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    if (!g_prof_free.empty()) {
+      pair = g_prof_free.back();
+      g_prof_free.pop_back();
+    } else if (hipEventCreate(&pair.beg) != hipSuccess || hipEventCreate(&pair.end) != hipSuccess) {
+      return;
+    }
+    pair.kind = kind;
+    on = hipEventRecord(pair.beg, st) == hipSuccess;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(pair.end, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_live.push_back(pair);
+  }
+};
 
 // ---------------------------------------------------------------------------
 // host dispatch
@@ -78,9 +116,11 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
   auto at = static_cast<const LT*>(attn);
   auto o = static_cast<VT*>(out);
   if (lg < 0) {
+    ProfScope prof(TRANSOAR_PROF_FWD_GENERIC, st);
     hipLaunchKernelGGL((msda3d_fwd_generic<VT, LT>), dim3(n_blocks), block, 0, st, v, shapes, lsi,
                        lo, at, o, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
   } else {
+    ProfScope prof(TRANSOAR_PROF_FWD, st);
     const dim3 grid(((n_blocks + 7) / 8) * 8);
     const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
 #define TRANSOAR_FWD(LG)                                                                      \
@@ -129,6 +169,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 
   if (lg < 0) {
     // scatter with fp atomics into a zeroed accumulator of type A
+    ProfScope prof(TRANSOAR_PROF_BWD_GENERIC, st);
     A* gv = sizeof(VT) == 2 ? static_cast<A*>(workspace) : static_cast<A*>(grad_value);
     TRANSOAR_CHECK_HIP(hipMemsetAsync(gv, 0, sizeof(A) * value_elems, st));
     hipLaunchKernelGGL((msda3d_bwd_generic<VT, LT>), dim3(n_blocks), block, 0, st, v, shapes, lsi,
@@ -148,9 +189,12 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 #define TRANSOAR_BWDQ(LG)                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
                      at, go, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_items, n_blocks)
-  if (lg == 3) TRANSOAR_BWDQ(3);
-  else if (lg == 4) TRANSOAR_BWDQ(4);
-  else TRANSOAR_BWDQ(5);
+  {
+    ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+    if (lg == 3) TRANSOAR_BWDQ(3);
+    else if (lg == 4) TRANSOAR_BWDQ(4);
+    else TRANSOAR_BWDQ(5);
+  }
 #undef TRANSOAR_BWDQ
 
   // 2. sort the sampling points by cell
@@ -163,16 +207,25 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
   TRANSOAR_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * w.n_scan, st));
   const dim3 pgrid(static_cast<unsigned>((w.n_points + 255) / 256));
-  hipLaunchKernelGGL((msda3d_cell_count<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
-                     rank, d.M, d.L, d.Lq, d.P, w.n_points);
+  {
+    ProfScope prof(TRANSOAR_PROF_CELL_COUNT, st);
+    hipLaunchKernelGGL((msda3d_cell_count<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                       rank, d.M, d.L, d.Lq, d.P, w.n_points);
+  }
+  {
+  ProfScope prof(TRANSOAR_PROF_SCAN, st);
   hipLaunchKernelGGL(msda3d_scan_tiles, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0,
                      st, count, tile_sums, static_cast<int>(w.n_scan));
   hipLaunchKernelGGL(msda3d_scan_tile_sums, dim3(1), dim3(kScanThreads), 0, st, tile_sums,
                      static_cast<int>(w.n_tiles));
   hipLaunchKernelGGL(msda3d_scan_add, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0, st,
                      count, tile_sums, static_cast<int>(w.n_scan));
-  hipLaunchKernelGGL((msda3d_cell_fill<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
-                     rank, recs, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
+  }
+  {
+    ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
+    hipLaunchKernelGGL((msda3d_cell_fill<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                       rank, recs, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
+  }
 
   // 3. grad_value rows
   const long n_rows = static_cast<long>(d.N) * d.S * d.M;
@@ -181,9 +234,12 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 #define TRANSOAR_PULL(LG)                                                                        \
   hipLaunchKernelGGL((msda3d_bwd_value_pull<VT, A, LG>), rgrid, block, 0, st, go, shapes, lsi, count, \
                      recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks)
-  if (lg == 3) TRANSOAR_PULL(3);
-  else if (lg == 4) TRANSOAR_PULL(4);
-  else TRANSOAR_PULL(5);
+  {
+    ProfScope prof(TRANSOAR_PROF_PULL, st);
+    if (lg == 3) TRANSOAR_PULL(3);
+    else if (lg == 4) TRANSOAR_PULL(4);
+    else TRANSOAR_PULL(5);
+  }
 #undef TRANSOAR_PULL
   return static_cast<int>(hipGetLastError());
 }
@@ -282,4 +338,33 @@ extern "C" const char* transoar_msda3d_strerror(int code) {
   }
 }
 
-extern "C" int transoar_msda3d_abi_version(void) { return 2; }
+extern "C" void transoar_msda3d_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+}
+
+extern "C" int transoar_msda3d_profile_read(double* total_ms, long* launches) {
+  std::vector<ProfPair> live;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    live.swap(g_prof_live);
+  }
+  for (int k = 0; k < TRANSOAR_PROF_KINDS; ++k) {
+    total_ms[k] = 0.0;
+    launches[k] = 0;
+  }
+  int rc = 0;
+  for (const ProfPair& p : live) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(p.end);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.beg, p.end);
+    if (e != hipSuccess) { rc = static_cast<int>(e); continue; }
+    total_ms[p.kind] += ms;
+    launches[p.kind] += 1;
+  }
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_free.insert(g_prof_free.end(), live.begin(), live.end());
+  return rc;
+}
+
+extern "C" int transoar_msda3d_abi_version(void) { return 3; }

@@ -1,0 +1,119 @@
+"""Data-parallel gradient exchange for the training step: one process per GPU,
+``torch.distributed`` ("nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+The reference is single-process (scripts/train.py:28 pins one device; no
+collective anywhere), so this has no counterpart to mirror; the
+contract it implements is "N replicas on batch shards == one process on the
+concatenated batch":
+
+  * the loss normalisers (number of target boxes / valid class slots,
+    criterion.py:96) are summed over ranks first (one 2-element all-reduce),
+  * gradients are SUMMED over ranks (not averaged).
+
+Mechanics, chosen for xGMI (7 point-to-point links per GPU: a few large
+messages, launched early):
+  * parameters are packed, in reverse registration order (~ the order autograd
+    finishes them: heads -> neck -> FPN decoder -> encoder stage 5 ... 0), into
+    a few flat fp32 buckets (default 48 MiB; the model has ~217 MB of grads);
+    ``param.grad`` are views into the buckets, so there is no pack/unpack copy;
+  * a post-accumulate-grad hook counts a bucket's parameters down and launches
+    its all-reduce asynchronously the moment the last one lands, so the
+    exchange of the big early buckets (encoder stage 5: 96 MB) hides behind the
+    expensive full-resolution backbone backward that is still to run;
+  * parameters that never receive a gradient (the dead ``cross_attn.q_proj``,
+    SURVEY F8) are discovered in the first step and excluded afterwards.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params, device, dtype):
+        self.params = params
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, device=device, dtype=dtype)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.expected = len(params)
+        self.pending = self.expected
+        self.handle = None
+
+
+class GradientAllReducer:
+    def __init__(self, module, process_group=None, bucket_bytes=48 << 20):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets, self._bucket_of, self._hooks = [], {}, []
+        self._fired, self._first_step = set(), True
+        if not self.active:
+            return
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_bytes:
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._add_bucket(cur)
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _add_bucket(self, params):
+        b = _Bucket(list(params), params[0].device, params[0].dtype)
+        for p, v in zip(b.params, b.views):
+            self._bucket_of[p] = b
+            p.grad = v
+        self.buckets.append(b)
+
+    # ---- per step -----------------------------------------------------------
+    def reduce_counts(self, counts):
+        """Sum a small tensor of loss normalisers over the ranks (no-op for one rank)."""
+        if self.active:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        return counts
+
+    def begin(self):
+        """Call before forward/backward: zero the gradient buckets."""
+        if not self.active:
+            for p in self.params:
+                p.grad = None
+            return
+        for b in self.buckets:
+            b.flat.zero_()
+            b.pending = b.expected
+            b.handle = None
+            for p, v in zip(b.params, b.views):     # someone may have replaced .grad
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+        self._fired.clear()
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        if self._first_step:
+            self._fired.add(p)
+        b.pending -= 1
+        if b.pending == 0:
+            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Call after backward, before the optimizer: wait for every bucket."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if b.handle is None:     # first step only: a parameter without gradient held it back
+                b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b.handle.wait()
+        if self._first_step:
+            for b in self.buckets:
+                b.expected = sum(1 for p in b.params if p in self._fired)
+            self._first_step = False
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

@@ -1,0 +1,187 @@
+"""Focused Decoder neck: per-organ queries, self-attention among the queries,
+cross-attention restricted to each organ's region of interest, FFN.
+
+Stays PyTorch-ROCm host code by design (BASELINE.json north_star).  Mirrors
+transoar/models/necks/focused_decoder.py (FocusedDecoder :12-59,
+FocusedDecoderModel :61-80, FocusedDecoderLayer :82-189, FocusedAttn :192-262)
+including its quirks:
+  * FocusedAttn projects the queries with ``k_proj`` (:235), so ``q_proj`` is a
+    parameter that never gets a gradient -- kept for checkpoint
+    compatibility and parity;
+  * the RoI mask is built from bbox_properties[*]['attn_area'] with floor/ceil
+    on a hard-coded level shape table (:99-117, :138-159).
+Host-side differences: the mask is a registered (non-persistent) buffer held as
+an additive 0/-inf tensor instead of a ``.cuda()`` attribute rewritten in place
+every call (:243-245), and the masked attention goes through
+``scaled_dot_product_attention`` so the (N, heads, Q, 102400) score tensor is
+not materialised four times per layer.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_LEVEL_SHAPES = {
+    20: {"P0": (160, 160, 256), "P1": (80, 80, 128), "P2": (40, 40, 64), "P3": (20, 20, 32),
+         "P4": (10, 10, 16), "P5": (5, 5, 8)},
+    None: {"P0": (256, 256, 128), "P1": (128, 128, 64), "P2": (64, 64, 32), "P3": (32, 32, 16),
+           "P4": (16, 16, 8), "P5": (8, 8, 4)},
+}
+
+
+def _activation(name):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[name]
+    except KeyError:
+        raise RuntimeError("activation should be relu/gelu, not %s." % name)
+
+
+class FocusedAttn(nn.Module):
+    def __init__(self, dim, num_heads, attn_mask, qkv_bias=None, qk_scale=None, attn_drop=0,
+                 proj_drop=0, use_pos_bias=False, return_weights=True):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.ret_weights = return_weights
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        bias = bool(qkv_bias)
+        self.q_proj = nn.Linear(dim, dim, bias=bias)   # dead: see module docstring
+        self.k_proj = nn.Linear(dim, dim, bias=bias)
+        self.v_proj = nn.Linear(dim, dim, bias=bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if use_pos_bias:
+            self.pos_bias = nn.Parameter(torch.zeros_like(attn_mask, dtype=torch.float))
+            nn.init.trunc_normal_(self.pos_bias, std=.02)
+        else:
+            self.pos_bias = None
+
+    def forward(self, q, k, v, mask=None, need_weights=False):
+        """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf.
+        Returns (out, weights or None)."""
+        b, n_kv, c = k.shape
+        n_q = q.shape[1]
+        h, hd = self.num_heads, c // self.num_heads
+        kh = self.k_proj(k).view(b, n_kv, h, hd).transpose(1, 2)
+        vh = self.v_proj(v).view(b, n_kv, h, hd).transpose(1, 2)
+        qh = self.k_proj(q).view(b, n_q, h, hd).transpose(1, 2)     # sic: k_proj
+        bias = mask
+        if self.pos_bias is not None:
+            bias = self.pos_bias if bias is None else bias + self.pos_bias
+        weights = None
+        if need_weights:
+            attn = (qh * self.scale) @ kh.transpose(-2, -1)
+            if bias is not None:
+                attn = attn + bias
+            attn = attn.softmax(dim=-1)
+            weights = attn
+            x = self.attn_drop(attn) @ vh
+        else:
+            if bias is not None:
+                bias = bias.to(qh.dtype)
+            x = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias,
+                                               dropout_p=self.attn_drop.p if self.training else 0.0,
+                                               scale=self.scale)
+        x = x.transpose(1, 2).reshape(b, n_q, c)
+        return self.proj_drop(self.proj(x)), weights
+
+
+class FocusedDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_heads=8,
+                 config=None, bbox_props=None):
+        super().__init__()
+        self.config, self.bbox_props = config, bbox_props
+        self.num_queries_per_organ = int(config["num_queries"] / config["num_organs"])
+        assert self.num_queries_per_organ in [1, 7, 27, 54]
+        table = _LEVEL_SHAPES[20] if config["num_organs"] == 20 else _LEVEL_SHAPES[None]
+        self.input_shape = torch.tensor(table[config["input_levels"]])
+
+        self.register_buffer("attn_mask", self.generate_attn_masks(), persistent=False)
+        self.register_buffer("attn_bias", torch.zeros(self.attn_mask.shape).masked_fill_(
+            self.attn_mask, float("-inf")), persistent=False)
+        self.cross_attn = FocusedAttn(d_model, n_heads, self.attn_mask, proj_drop=0.1)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def generate_attn_masks(self, padding=0):
+        """bool (num_queries, prod(level shape)): True = key outside the organ's
+        attention volume.  (focused_decoder.py:138-159)"""
+        shape = self.input_shape
+        n_q = self.config["num_queries"]
+        if not self.config["restrict_attn"]:
+            return torch.zeros(n_q, int(shape.prod()), dtype=torch.bool)
+        vols = torch.stack([torch.tensor(p["attn_area"], dtype=torch.float32) for p in self.bbox_props.values()])
+        vols = vols.repeat_interleave(self.num_queries_per_organ, dim=0)         # x1 y1 z1 x2 y2 z2
+        both = shape.repeat(2).float()
+        vols = (vols * both - padding).clamp(min=torch.zeros(6), max=both)
+        lo = vols[:, :3].floor().int()
+        hi = vols[:, 3:].ceil().int()
+        mask = torch.ones(n_q, *shape.tolist(), dtype=torch.bool)
+        for q in range(n_q):
+            mask[q, lo[q, 0]:hi[q, 0], lo[q, 1]:hi[q, 1], lo[q, 2]:hi[q, 2]] = False
+        return mask.flatten(1)
+
+    def forward(self, tgt, query_pos, src_pos, src, need_weights=False):
+        q = k = tgt if query_pos is None else tgt + query_pos
+        sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
+                            need_weights=False)[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(sa))
+
+        q = tgt if query_pos is None else tgt + query_pos
+        k = src if src_pos is None else src + src_pos
+        ca, weights = self.cross_attn(q, k, src, mask=self.attn_bias, need_weights=need_weights)
+        tgt = self.norm1(tgt + self.dropout1(ca))
+
+        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(ffn)), weights
+
+
+class FocusedDecoderModel(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = nn.ModuleList(copy.deepcopy(decoder_layer) for _ in range(num_layers))
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, src, src_pos, query_pos=None):
+        out, stack = tgt, []
+        for layer in self.layers:
+            out, _ = layer(out, query_pos, src_pos, src)
+            if self.return_intermediate:
+                stack.append(out)
+        return torch.stack(stack) if self.return_intermediate else out
+
+
+class FocusedDecoder(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_decoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", return_intermediate_dec=False, bbox_props=None, config=None):
+        super().__init__()
+        self.bbox_props, self.config = bbox_props, config
+        self.d_model, self.nhead = d_model, nhead
+        layer = FocusedDecoderLayer(d_model, dim_feedforward, dropout, activation, nhead, config, bbox_props)
+        self.decoder = FocusedDecoderModel(layer, num_decoder_layers, return_intermediate_dec)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, query_embed, pos):
+        """src/pos (N, C, D, H, W); query_embed (Q, 2C) = [query_pos | tgt]
+        -> (layers, N, Q, C)"""
+        assert query_embed is not None
+        src = src.flatten(2).transpose(1, 2)
+        pos = pos.flatten(2).transpose(1, 2)
+        n, _, c = src.shape
+        query_pos, tgt = query_embed.split(c, dim=1)
+        return self.decoder(tgt[None].expand(n, -1, -1), src, pos, query_pos[None].expand(n, -1, -1))

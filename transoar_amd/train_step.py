@@ -1,0 +1,69 @@
+"""One training step of TransoarNet: autocast forward, weighted loss sum,
+backward (with the data-parallel gradient exchange overlapped), AdamW.
+
+The unit the headline metric times.  Follows the step of
+transoar/trainer.py:54-92 and the optimiser set-up of scripts/train.py:52-65
+(two parameter groups: ``_backbone`` at lr_backbone, the rest at lr; AdamW,
+weight decay 1e-4; optional gradient clipping), with these deliberate changes:
+  * bf16 autocast without a GradScaler (the reference uses fp16 + GradScaler on
+    CUDA; bf16 needs no loss scaling) -- fp32 master weights either way;
+  * no ``.item()`` in the step (the reference does six host syncs per step,
+    trainer.py:87-92): losses are returned as device tensors;
+  * targets are densified once per step (DenseTargets) and the loss
+    normalisers are all-reduced so N data-parallel replicas equal one process
+    on the concatenated batch.
+"""
+import torch
+
+from .data_parallel import GradientAllReducer
+from .matcher import DenseTargets
+
+
+def build_optimizer(model, config, fused=None):
+    backbone = [p for n, p in model.named_parameters() if "_backbone" in n and p.requires_grad]
+    rest = [p for n, p in model.named_parameters() if "_backbone" not in n and p.requires_grad]
+    if fused is None:
+        fused = all(p.is_cuda for p in backbone + rest)
+    return torch.optim.AdamW(
+        [{"params": backbone}, {"params": rest, "lr": float(config["lr"])}],
+        lr=float(config["lr_backbone"]), weight_decay=float(config["weight_decay"]), fused=fused)
+
+
+class TrainStep:
+    def __init__(self, model, criterion, config, optimizer=None, amp_dtype=torch.bfloat16,
+                 process_group=None, bucket_bytes=48 << 20):
+        self.model, self.criterion, self.config = model, criterion, config
+        self.optimizer = optimizer or build_optimizer(model, config)
+        self.amp_dtype = amp_dtype
+        self.reducer = GradientAllReducer(model, process_group, bucket_bytes)
+        self.num_classes = config["num_classes"]
+        self.device_type = next(model.parameters()).device.type
+
+    def loss(self, data, targets, seg_targets=None):
+        """-> (weighted total, dict of unweighted losses); forward only."""
+        if not isinstance(targets, DenseTargets):
+            targets = DenseTargets.from_list(targets, self.num_classes, data.device)
+        if self.reducer.active:
+            counts = torch.stack((torch.as_tensor(float(targets.num_boxes), device=data.device),
+                                  targets.present.sum().float()))
+            counts = self.reducer.reduce_counts(counts)
+            targets = DenseTargets(targets.boxes, targets.present, counts[0], counts[1])
+        enabled = self.amp_dtype is not None and self.amp_dtype != torch.float32
+        with torch.autocast(self.device_type, dtype=self.amp_dtype if enabled else torch.bfloat16, enabled=enabled):
+            out = self.model(data)
+            losses = self.criterion(out, targets, seg_targets, self.model._anchors)
+            coefs = self.config["loss_coefs"]
+            total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
+        return total, losses
+
+    def __call__(self, data, targets, seg_targets=None):
+        self.model.train()
+        self.reducer.begin()
+        total, losses = self.loss(data, targets, seg_targets)
+        total.backward()
+        self.reducer.finish()
+        max_norm = self.config.get("clip_max_norm", -1)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None], max_norm)
+        self.optimizer.step()
+        return total.detach(), losses
