@@ -32,6 +32,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The torch-side convolutions (everything that is not yet a hand-written kernel) go
+# through MIOpen, whose untuned fallback for these 3-D bf16 shapes is a naive
+# reference kernel (1.5 s per step for one layer).  miopen_db/ holds the user
+# find-db tuned once on an MI355X (python bench.py --miopen-benchmark with
+# MIOPEN_USER_DB_PATH pointing there); using it is plumbing, not product.
+_DB = os.path.join(ROOT, "miopen_db")
+if os.path.isdir(_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
+    os.environ["MIOPEN_USER_DB_PATH"] = _DB
+
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -83,6 +92,7 @@ def main():
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=420.0)
     args = ap.parse_args()
@@ -96,6 +106,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

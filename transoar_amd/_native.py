@@ -7,6 +7,12 @@ turn into a silently slower (or CPU) path.
 import ctypes
 import os
 
+# torch bundles its own libamdhip64.so.7 / libhsa-runtime64; it has to be in the
+# process BEFORE this library is dlopen'ed, so that both resolve to the same
+# HIP runtime (loading /opt/rocm's copy first leaves torch and the kernels on
+# two different runtimes: "no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libtransoar_msda3d.so"
 
