@@ -1,0 +1,77 @@
+/*
+ * transoar_conv3d.h -- C ABI of the gfx950 3x3x3 convolution kernels of the
+ * AttnFPN backbone (bf16 storage, fp32 accumulation on the matrix cores,
+ * channels-last NDHWC activations).
+ *
+ * These entry points replace the cuDNN convolutions PyTorch runs for
+ *   nn.Conv3d(k=3, pad=1, stride 1|2, bias=False)   encoder stages
+ *       transoar/models/backbones/encoder_blocks.py:28-48
+ *   nn.Conv3d(k=3, pad=1, bias=True)                 FPN output convs
+ *       transoar/models/backbones/attn_fpn.py:65-73, :126
+ * (forward, data gradient and weight gradient).  The Python module
+ * transoar_amd/conv3d.py is the autograd shim that binds them.
+ *
+ * All pointers are device pointers, 16-byte aligned; every call is
+ * asynchronous on `hip_stream`.  Returns 0, a hipError_t (> 0) or one of the
+ * negative codes below.
+ */
+#ifndef TRANSOAR_CONV3D_H
+#define TRANSOAR_CONV3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  TRANSOAR_CONV_OK = 0,
+  TRANSOAR_CONV_ERR_NULL = -1,
+  TRANSOAR_CONV_ERR_DIM = -2,       /* bad size, or a tensor >= 4 GiB (32-bit offsets) */
+  TRANSOAR_CONV_ERR_CHANNELS = -3   /* Cin % 8 or Cout % 4 (k3), Cout % 8 (c1)        */
+};
+
+/*
+ * y = conv3d(x, w, pad 1, stride) (+ bias), implicit GEMM.
+ *   x    (N, D, H, W, Cin)        bf16
+ *   wk   (27, Cout, Cin)          bf16, tap index = (kd*3 + kh)*3 + kw
+ *   bias (Cout) fp32 or NULL
+ *   y    (N, Do, Ho, Wo, Cout)    bf16, Do = (D-1)/stride + 1 ...
+ * dilated_input != 0 (stride must be 1): x is read as if zero-dilated by 2
+ * (only even coordinates exist) and the output grid is (2D, 2H, 2W): with
+ * flipped, in/out-swapped weights this is the data gradient of a stride-2
+ * layer.  The data gradient of a stride-1 layer is a plain call with those
+ * weights.
+ */
+int transoar_conv3d_k3_forward(const void* x, const void* wk, const float* bias, void* y,
+                               int N, int D, int H, int W, int Cin, int Cout, int stride,
+                               int dilated_input, void* hip_stream);
+
+/*
+ * dW (27, Cout, Cin) fp32 += sum over voxels  dy[voxel][cout] * x[voxel+tap][cin]
+ * (dw must be zeroed by the caller; accumulated with fp32 atomics).
+ *   gyT  (Cout, N, Do, Ho, Wo)        bf16, channels FIRST
+ *   xT3  (3, Cin, N, D, H, Wo)        bf16, channels first, three copies pre-
+ *        shifted (and for stride 2 decimated) along W:
+ *        xT3[kw][ci][n][d][h][wo] = x[n][d][h][stride*wo + kw - 1][ci], 0 outside
+ *   W here is the row length of xT3 and must equal Wo; Wo % 8 == 0.
+ *   stride_dh is the layer's stride, applied along D and H.
+ */
+int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N, int D, int H,
+                             int W, int Cin, int Do, int Ho, int Wo, int Cout, int stride_dh,
+                             void* hip_stream);
+
+/*
+ * First layer, Cin == 1, stride 1: stencil.
+ *   x (N, D, H, W) bf16 ; w (27, Cout) fp32 ; y (N, D, H, W, Cout) bf16
+ */
+int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H,
+                               int W, int Cout, void* hip_stream);
+
+int transoar_conv3d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSOAR_CONV3D_H */

@@ -17,6 +17,7 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"
 # library name -> sources (relative to csrc/)
 LIBS = {
     "libtransoar_msda3d.so": ["msda3d.hip"],
+    "libtransoar_conv3d.so": ["conv3d.hip"],
 }
 
 

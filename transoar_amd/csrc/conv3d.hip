@@ -1,0 +1,449 @@
+// 3x3x3 convolution (pad 1, stride 1 or 2) of the AttnFPN backbone on gfx950:
+// implicit GEMM on the bf16 matrix cores, fp32 accumulation, channels-last.
+//
+// Replaces the cuDNN calls behind nn.Conv3d in the reference's encoder stages
+// (transoar/models/backbones/encoder_blocks.py:28-48) and FPN output convs
+// (transoar/models/backbones/attn_fpn.py:65-73,126).  Three kernels:
+//
+//   conv3d_k3_igemm   y = conv(x, w) (+bias).  Also computes dgrad: for a
+//                     stride-1 layer dx = conv(dy, flipped/transposed w); for a
+//                     stride-2 layer the same over the zero-dilated dy (DIL).
+//                     GEMM view: D[cout][voxel] = sum_K W[cout][K] X[K][voxel],
+//                     K = (tap, cin) walked in chunks of 8 input channels.
+//   conv3d_k3_wgrad   dW[cout][(tap,cin)] = sum_voxels dy[voxel][cout] *
+//                     x[voxel+tap][cin]; here K = voxels, so the operands come
+//                     from channels-FIRST copies (W-contiguous), the x copy
+//                     pre-shifted along W for the three kw taps.
+//   conv3d_c1_fwd     Cin == 1 first layer: a stencil, HBM-bound, no MFMA.
+//
+// No LDS tiling yet: every MFMA operand fragment is one 16-byte buffer load per
+// lane (8 bf16 along the contraction axis, exactly the 32x32x16 fragment), out
+// of range taps / channels are handled by the buffer's hardware bounds check
+// (offset -> 0xfffffff0 -> zeros), and each wave register-blocks MT x NT tiles
+// of 32x32 so a fragment is reused MT or NT times.  D is computed transposed
+// (rows = cout) so that a lane ends up with 4 consecutive output channels of
+// one voxel per accumulator quad -> 8-byte stores into the NDHWC output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_conv3d.h"
+
+namespace transoar {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4c = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2c = __attribute__((ext_vector_type(2))) unsigned int;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) {
+  return __uint_as_float(static_cast<unsigned int>(b) << 16);
+}
+
+constexpr unsigned kOOB = 0xfffffff0u;
+
+struct ConvGeom {
+  int N, D, H, W, Cin;        // input (for DIL: the un-dilated dy grid)
+  int Do, Ho, Wo, Cout;       // output
+  int CinP;                   // Cin rounded up to 8 (row length of the packed weights)
+  int stride;                 // 1 or 2 (always 1 when DIL)
+};
+
+// ---------------------------------------------------------------------------
+// implicit GEMM, K = (tap, cin)
+//   x   (N, D, H, W, Cin) bf16          wk (27, Cout, CinP) bf16
+//   y   (N, Do, Ho, Wo, Cout) bf16      bias (Cout) fp32 or null
+// DIL: input is the zero-dilated (x2) grid of x; coordinate u maps to u/2 when
+// even (transposed convolution of a stride-2 layer).
+// ---------------------------------------------------------------------------
+template <int MT, int NT, bool DIL>
+__global__ __launch_bounds__(256) void conv3d_k3_igemm(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ wk,
+                                                       const float* __restrict__ bias,
+                                                       unsigned short* __restrict__ y, ConvGeom g,
+                                                       long n_vox, unsigned x_bytes, unsigned w_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;       // voxel column inside an M tile / cout row inside an N tile
+  const int half = lane >> 5;      // which 8-wide K chunk of the 16-wide MFMA step
+  const long m_base = (static_cast<long>(blockIdx.x) * 4 + wave) * (32 * MT);
+  if (m_base >= n_vox) return;
+  const int n_base = blockIdx.y * (32 * NT);
+
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x), 0, static_cast<int>(x_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wk), 0, static_cast<int>(w_bytes), 0x00020000);
+
+  // per M tile: this lane's output voxel -> linear index of input tap (0,0,0) and validity bits
+  int base_lin[MT];      // !DIL: ((n*D + id0)*H + ih0)*W + iw0   (may be negative)
+  int okbits[MT];        // bit kd | bit 3+kh | bit 6+kw : that tap coordinate is in range
+  int sd[MT][3], sh[MT][3], sw[MT][3];   // DIL only: source coordinates per tap index (or -1)
+  int nD[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const long v = m_base + t * 32 + col;
+    const bool live = v < n_vox;
+    const long vv = live ? v : 0;
+    const int ow = static_cast<int>(vv % g.Wo);
+    const long r1 = vv / g.Wo;
+    const int oh = static_cast<int>(r1 % g.Ho);
+    const long r2 = r1 / g.Ho;
+    const int od = static_cast<int>(r2 % g.Do);
+    const int n = static_cast<int>(r2 / g.Do);
+    const int id0 = od * g.stride - 1, ih0 = oh * g.stride - 1, iw0 = ow * g.stride - 1;
+    int bits = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (DIL) {
+        const int ud = id0 + k, uh = ih0 + k, uw = iw0 + k;
+        sd[t][k] = (ud >= 0 && !(ud & 1) && (ud >> 1) < g.D) ? (ud >> 1) : -1;
+        sh[t][k] = (uh >= 0 && !(uh & 1) && (uh >> 1) < g.H) ? (uh >> 1) : -1;
+        sw[t][k] = (uw >= 0 && !(uw & 1) && (uw >> 1) < g.W) ? (uw >> 1) : -1;
+      } else {
+        bits |= (static_cast<unsigned>(id0 + k) < static_cast<unsigned>(g.D) ? 1 : 0) << k;
+        bits |= (static_cast<unsigned>(ih0 + k) < static_cast<unsigned>(g.H) ? 1 : 0) << (3 + k);
+        bits |= (static_cast<unsigned>(iw0 + k) < static_cast<unsigned>(g.W) ? 1 : 0) << (6 + k);
+      }
+    }
+    okbits[t] = live ? bits : 0;
+    if (DIL && !live) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sd[t][k] = -1;
+    }
+    nD[t] = n * g.D;
+    base_lin[t] = ((n * g.D + id0) * g.H + ih0) * g.W + iw0;
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+  const int cpt = g.CinP >> 3;            // 8-channel chunks per tap
+  const int n_chunks = 27 * cpt;
+  const int HW = g.H * g.W;
+  const unsigned cin_bytes = static_cast<unsigned>(g.Cin) * 2u;
+
+  // this lane-half's chunk: q = 2*step + half -> (tap = kd,kh,kw ; c8)
+  int c8 = half, kd = 0, kh = 0, kw = 0, tap = 0;
+  while (c8 >= cpt) { c8 -= cpt; ++tap; if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; ++kd; } } }
+
+  for (int q = half; q < n_chunks + half; q += 2) {
+    const bool chunk_ok = q < n_chunks && c8 * 8 < g.Cin;
+    // weight fragments: A[i = cout][k] = wk[tap][cout][c8*8 .. +8]
+    bf16x8 wf[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int co = n_base + a * 32 + col;
+      const unsigned off = (co < g.Cout && q < n_chunks)
+                               ? (static_cast<unsigned>(tap * g.Cout + co) * g.CinP + c8 * 8) * 2u
+                               : kOOB;
+      wf[a] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+    }
+    // activation fragments: B[k][j = voxel] = x[voxel @ tap][c8*8 .. +8]
+    bf16x8 xf[MT];
+    const int delta = kd * HW + kh * g.W + kw;
+    const int need = (1 << kd) | (8 << kh) | (64 << kw);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      unsigned off;
+      if (DIL) {
+        const int d = kd == 0 ? sd[t][0] : (kd == 1 ? sd[t][1] : sd[t][2]);
+        const int h = kh == 0 ? sh[t][0] : (kh == 1 ? sh[t][1] : sh[t][2]);
+        const int w = kw == 0 ? sw[t][0] : (kw == 1 ? sw[t][1] : sw[t][2]);
+        const bool ok = chunk_ok && (d | h | w) >= 0;
+        const int lin = ((nD[t] + d) * g.H + h) * g.W + w;
+        off = ok ? static_cast<unsigned>(lin) * cin_bytes + c8 * 16 : kOOB;
+      } else {
+        const bool ok = chunk_ok && (okbits[t] & need) == need;
+        off = ok ? static_cast<unsigned>(base_lin[t] + delta) * cin_bytes + c8 * 16 : kOOB;
+      }
+      xf[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[t], acc[a][t], 0, 0, 0);
+    // advance this half's chunk by 2
+    c8 += 2;
+    while (c8 >= cpt) { c8 -= cpt; ++tap; if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; ++kd; } } }
+  }
+
+  // epilogue: D[i = cout][j = voxel]; lane: col j, rows (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const long v = m_base + t * 32 + col;
+    if (v >= n_vox) continue;
+    unsigned short* yrow = y + v * g.Cout;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int co = n_base + a * 32 + 8 * gq + 4 * half;
+        if (co < g.Cout) {      // Cout % 4 == 0 (checked on the host)
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[a][t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
+          u32x2c pk;
+          pk[0] = static_cast<unsigned>(f2bf(o[0])) | (static_cast<unsigned>(f2bf(o[1])) << 16);
+          pk[1] = static_cast<unsigned>(f2bf(o[2])) | (static_cast<unsigned>(f2bf(o[3])) << 16);
+          *reinterpret_cast<u32x2c*>(yrow + co) = pk;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient, K = voxels.
+//   gyT  (Cout, V)       bf16, V = N*Do*Ho*Wo, voxel-contiguous (channels first)
+//   xT3  (3, Cin, N, D, H, W) bf16: xT3[kw][ci][n][d][h][w] = x[n][d][h][w+kw-1][ci]
+//        (zero outside) -- the three W-shifts are materialised so every fragment
+//        is an aligned 16-byte load.  stride 1 only in this layout (stride-2
+//        layers pass a W-decimated copy, see the host shim).
+//   dw   (27, Cout, CinP) fp32, accumulated with atomics over the voxel split.
+// D[i = cout][j = (tap,ci)] tiles; a wave owns NT column tiles and walks a
+// range of voxel rows (n, d, h) in steps of 16 voxels along W.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad(const unsigned short* __restrict__ gyT,
+                                                       const unsigned short* __restrict__ xT3,
+                                                       float* __restrict__ dw, ConvGeom g,
+                                                       int rows_per_block, unsigned gy_bytes,
+                                                       unsigned x_bytes) {
+  // geometry here: output grid (Do,Ho,Wo) == the gy grid; input grid (D,H,Wd) where Wd is
+  // the (possibly decimated) W extent of xT3 rows that line up 1:1 with gy columns.
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  const int n_cols = 27 * g.Cin;                       // (tap, ci) columns
+  const int col_tiles = (n_cols + 31) >> 5;
+  const int ct0 = (blockIdx.y * 4 + wave) * NT;        // first column tile of this wave
+  if (ct0 >= col_tiles) return;
+  const int co_base = blockIdx.z * 32;
+
+  const __amdgpu_buffer_rsrc_t gr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(gyT), 0, static_cast<int>(gy_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xT3), 0, static_cast<int>(x_bytes), 0x00020000);
+
+  const long V = static_cast<long>(g.N) * g.Do * g.Ho * g.Wo;
+  const long plane = static_cast<long>(g.N) * g.D * g.H * g.W;   // voxels per channel of xT3
+
+  // column -> (tap, ci): fixed per lane per tile
+  int kd[NT], kh[NT], kwv[NT], ci[NT];
+  bool col_ok[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int c = (ct0 + a) * 32 + col;
+    col_ok[a] = c < n_cols;
+    const int cc = col_ok[a] ? c : 0;
+    const int tap = cc / g.Cin;
+    ci[a] = cc - tap * g.Cin;
+    kd[a] = tap / 9;
+    kh[a] = (tap / 3) % 3;
+    kwv[a] = tap % 3;
+  }
+  const int co = co_base + col;
+  const bool co_ok = co < g.Cout;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const int n_rows = g.N * g.Do * g.Ho;                // (n, od, oh) rows of Wo voxels
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(row0 + rows_per_block, n_rows);
+  for (int row = row0; row < row1; ++row) {
+    const int oh = row % g.Ho;
+    const int r2 = row / g.Ho;
+    const int od = r2 % g.Do;
+    const int n = r2 / g.Do;
+    // input row for each column tile's tap
+    long xrow[NT];
+    bool row_ok[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int id = od * g.stride + kd[a] - 1, ih = oh * g.stride + kh[a] - 1;
+      row_ok[a] = col_ok[a] && static_cast<unsigned>(id) < static_cast<unsigned>(g.D) &&
+                  static_cast<unsigned>(ih) < static_cast<unsigned>(g.H);
+      xrow[a] = (static_cast<long>(kwv[a]) * g.Cin + ci[a]) * plane +
+                ((static_cast<long>(n) * g.D + id) * g.H + ih) * g.W;
+    }
+    const long grow = static_cast<long>(co) * V + static_cast<long>(row) * g.Wo;
+    for (int w0 = 0; w0 < g.Wo; w0 += 16) {
+      const int wk = w0 + 8 * half;                    // this lane-half's 8 voxels
+      const bool w_ok = wk < g.Wo;                     // Wo % 8 == 0 (host check)
+      const unsigned goff = (co_ok && w_ok) ? static_cast<unsigned>((grow + wk) * 2) : kOOB;
+      const bf16x8 gf = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gr, goff, 0, 0));
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const unsigned xoff = (row_ok[a] && w_ok) ? static_cast<unsigned>((xrow[a] + wk) * 2) : kOOB;
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, 0, 0));
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[a], 0, 0, 0);
+      }
+    }
+  }
+
+  // D[i = cout][j = column]; lane: column j = col, rows (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    if (!col_ok[a]) continue;
+    const int tap = kd[a] * 9 + kh[a] * 3 + kwv[a];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (o < g.Cout)
+        __hip_atomic_fetch_add(dw + (static_cast<long>(tap) * g.Cout + o) * g.CinP + ci[a], acc[a][r],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cin == 1 stencil: x (N,D,H,W) bf16, w (27, Cout) fp32, y (N,D,H,W,Cout) bf16.
+// One thread per output voxel: its 27 inputs sit in registers, the weights are
+// wave-uniform (scalar loads), output channels are produced 8 at a time.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __restrict__ x,
+                                                     const float* __restrict__ w,
+                                                     unsigned short* __restrict__ y, int N, int D, int H,
+                                                     int W, int Cout, long n_vox) {
+  const long v = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (v >= n_vox) return;
+  const int ow = static_cast<int>(v % W);
+  const long r1 = v / W;
+  const int oh = static_cast<int>(r1 % H);
+  const long r2 = r1 / H;
+  const int od = static_cast<int>(r2 % D);
+  const long nbase = (r2 / D) * D;
+  float xv[27];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int id = od + kd - 1, ih = oh + kh - 1, iw = ow + kw - 1;
+        const bool ok = static_cast<unsigned>(id) < static_cast<unsigned>(D) &&
+                        static_cast<unsigned>(ih) < static_cast<unsigned>(H) &&
+                        static_cast<unsigned>(iw) < static_cast<unsigned>(W);
+        xv[kd * 9 + kh * 3 + kw] = ok ? bf2f(x[((nbase + id) * H + ih) * W + iw]) : 0.f;
+      }
+  for (int c0 = 0; c0 < Cout; c0 += 8) {      // uniform loop: weights come through the scalar cache
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const float* wt = w + t * Cout + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += xv[t] * wt[e];
+    }
+    u32x4c pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      pk[e] = static_cast<unsigned>(f2bf(acc[2 * e])) | (static_cast<unsigned>(f2bf(acc[2 * e + 1])) << 16);
+    *reinterpret_cast<u32x4c*>(y + v * Cout + c0) = pk;
+  }
+}
+
+static inline bool fits32(long bytes) { return bytes > 0 && bytes < 0xfffffff0L; }
+
+}  // namespace transoar
+
+using namespace transoar;
+
+extern "C" int transoar_conv3d_k3_forward(const void* x, const void* wk, const float* bias, void* y, int N,
+                                          int D, int H, int W, int Cin, int Cout, int stride, int dilated_input,
+                                          void* hip_stream) {
+  if (!x || !wk || !y) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if ((Cin & 7) || (Cout & 3)) return TRANSOAR_CONV_ERR_CHANNELS;
+  if (!(stride == 1 || stride == 2) || (dilated_input && stride != 1)) return TRANSOAR_CONV_ERR_DIM;
+  ConvGeom g;
+  g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CinP = (Cin + 7) & ~7; g.stride = stride;
+  if (dilated_input) {       // output grid = 2x the input grid (transposed conv of a stride-2 layer)
+    g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W;
+  } else {
+    g.Do = (D - 1) / stride + 1; g.Ho = (H - 1) / stride + 1; g.Wo = (W - 1) / stride + 1;
+  }
+  const long n_vox = static_cast<long>(N) * g.Do * g.Ho * g.Wo;
+  const long x_bytes = static_cast<long>(N) * D * H * W * Cin * 2;
+  const long w_bytes = 27L * Cout * g.CinP * 2;
+  if (!fits32(x_bytes) || !fits32(w_bytes) || n_vox >= (1L << 31)) return TRANSOAR_CONV_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  auto xp = static_cast<const unsigned short*>(x);
+  auto wp = static_cast<const unsigned short*>(wk);
+  auto yp = static_cast<unsigned short*>(y);
+  // register blocking per wave: 4 voxel tiles x 1 cout tile (Cout <= 32) or 2 x 2 (64 accumulator
+  // registers either way, 3 waves per SIMD to cover the load latency)
+  const bool wide = Cout > 32;
+  const int MT = wide ? 2 : 4, NT = wide ? 2 : 1;
+  const dim3 grid(static_cast<unsigned>((n_vox + 4 * 32 * MT - 1) / (4 * 32 * MT)),
+                  static_cast<unsigned>((Cout + 32 * NT - 1) / (32 * NT)));
+#define TRANSOAR_CONV(MTV, NTV, DILV)                                                                    \
+  hipLaunchKernelGGL((conv3d_k3_igemm<MTV, NTV, DILV>), grid, dim3(256), 0, st, xp, wp, bias, yp, g, n_vox, \
+                     static_cast<unsigned>(x_bytes), static_cast<unsigned>(w_bytes))
+  if (dilated_input) { if (wide) TRANSOAR_CONV(2, 2, true); else TRANSOAR_CONV(4, 1, true); }
+  else { if (wide) TRANSOAR_CONV(2, 2, false); else TRANSOAR_CONV(4, 1, false); }
+#undef TRANSOAR_CONV
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N, int D, int H, int W,
+                                        int Cin, int Do, int Ho, int Wo, int Cout, int stride_dh,
+                                        void* hip_stream) {
+  if (!gyT || !xT3 || !dw) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Wo & 7) || W != Wo)
+    return TRANSOAR_CONV_ERR_DIM;
+  ConvGeom g;
+  g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CinP = (Cin + 7) & ~7;
+  g.Do = Do; g.Ho = Ho; g.Wo = Wo; g.stride = stride_dh;
+  const long gy_bytes = static_cast<long>(Cout) * N * Do * Ho * Wo * 2;
+  const long x_bytes = 3L * Cin * N * D * H * W * 2;
+  if (!fits32(gy_bytes) || !fits32(x_bytes)) return TRANSOAR_CONV_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  constexpr int NT = 4;
+  const int col_tiles = (27 * Cin + 31) / 32;
+  const int n_rows = N * Do * Ho;
+  // split the voxel rows so the grid has a few thousand workgroups
+  const int wave_groups = (col_tiles + 4 * NT - 1) / (4 * NT);
+  const int co_tiles = (Cout + 31) / 32;
+  int splits = 4096 / (wave_groups * co_tiles);
+  splits = splits < 1 ? 1 : (splits > n_rows ? n_rows : splits);
+  const int rows_per_block = (n_rows + splits - 1) / splits;
+  const dim3 grid(static_cast<unsigned>((n_rows + rows_per_block - 1) / rows_per_block),
+                  static_cast<unsigned>(wave_groups), static_cast<unsigned>(co_tiles));
+  hipLaunchKernelGGL((conv3d_k3_wgrad<NT>), grid, dim3(256), 0, st, static_cast<const unsigned short*>(gyT),
+                     static_cast<const unsigned short*>(xT3), dw, g, rows_per_block,
+                     static_cast<unsigned>(gy_bytes), static_cast<unsigned>(x_bytes));
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H, int W,
+                                          int Cout, void* hip_stream) {
+  if (!x || !w || !y) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (Cout & 7) return TRANSOAR_CONV_ERR_CHANNELS;
+  const long n_vox = static_cast<long>(N) * D * H * W;
+  hipLaunchKernelGGL(conv3d_c1_fwd, dim3(static_cast<unsigned>((n_vox + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(x), w,
+                     static_cast<unsigned short*>(y), N, D, H, W, Cout, n_vox);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_abi_version(void) { return 1; }
