@@ -1,0 +1,49 @@
+"""GPU: the implicit-GEMM 3x3x3 convolution kernels against PyTorch's fp32
+convolution on the same bf16-rounded inputs.  Tolerance: outputs are rounded
+to bf16 (2^-8 relative to the tensor's max); weight gradients are fp32 sums of
+bf16 products (1e-3 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-300)
+
+
+CASES = [  # N, Cin, Cout, D, H, W, stride, bias
+    (2, 24, 24, 6, 10, 16, 1, False), (1, 24, 48, 8, 8, 16, 2, False), (2, 48, 96, 4, 6, 16, 2, False),
+    (1, 96, 96, 5, 5, 8, 1, False), (1, 96, 384, 4, 4, 8, 1, True), (2, 8, 40, 3, 7, 24, 1, True),
+    (1, 1, 24, 6, 10, 16, 1, False), (1, 192, 64, 2, 2, 8, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_k3_forward_backward(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd.conv3d import Conv3dK3
+    n, ci, co, d, h, w, s, bias = case
+    torch.manual_seed(ci * 1000 + co)
+    conv = Conv3dK3(ci, co, 3, stride=s, padding=1, bias=bias).cuda()
+    x = torch.randn(n, ci, d, h, w, device="cuda").to(torch.bfloat16).requires_grad_(ci != 1)
+    wb = conv.weight.detach().to(torch.bfloat16).float()
+    y = conv(x)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last_3d)
+    xr = x.detach().float().requires_grad_(ci != 1)
+    wr = wb.clone().requires_grad_()
+    br = conv.bias.detach().float().clone().requires_grad_() if bias else None
+    yr = F.conv3d(xr, wr, br, stride=s, padding=1)
+    assert tuple(y.shape) == tuple(yr.shape)
+    assert relerr(y, yr) <= 2.0 ** -7
+    g = torch.randn_like(yr).to(torch.bfloat16)
+    y.backward(g)
+    yr.backward(g.float())
+    assert relerr(conv.weight.grad, wr.grad) <= 2e-3
+    if bias:
+        assert relerr(conv.bias.grad, br.grad) <= 2e-3
+    if ci != 1:
+        assert relerr(x.grad, xr.grad) <= 2.0 ** -7

@@ -18,6 +18,7 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"
 LIBS = {
     "libtransoar_msda3d.so": ["msda3d.hip"],
     "libtransoar_conv3d.so": ["conv3d.hip"],
+    "libtransoar_instnorm.so": ["instnorm.hip"],
 }
 
 

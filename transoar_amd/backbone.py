@@ -11,6 +11,8 @@ The Swin encoder (``use_encoder_attn``) is outside this build's scope
 import torch
 from torch import nn
 
+from . import instnorm
+from .conv3d import Conv3dK3
 from .position_encoding import PositionEmbeddingLearned3D, PositionEmbeddingSine3D
 from .refine_block import DecoderDefAttnBlock
 
@@ -23,17 +25,32 @@ class EncoderCnnBlock(nn.Module):
                  affine=True, eps=1e-05):
         super().__init__()
         kernel_size, stride = tuple(kernel_size), tuple(stride)
+        # same Sequential layout as the reference (checkpoint keys _block.{0,1,3,4}.*); the
+        # convolutions are Conv3dK3 (nn.Conv3d subclasses with a hand-written bf16 GPU path)
         self._block = nn.Sequential(
-            nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias),
+            Conv3dK3(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias),
             nn.InstanceNorm3d(out_channels, affine=affine, eps=eps),
             nn.ReLU(inplace=True),
-            nn.Conv3d(out_channels, out_channels, kernel_size, stride=1, padding=padding, bias=bias),
+            Conv3dK3(out_channels, out_channels, kernel_size, stride=1, padding=padding, bias=bias),
             nn.InstanceNorm3d(out_channels, affine=affine, eps=eps),
             nn.ReLU(inplace=True),
         )
+        self._affine = affine
+
+    fused_norm = True      # class switch (A/B against MIOpen's batch-norm kernels)
+
+    def _norm_relu(self, x, norm):
+        if (EncoderCnnBlock.fused_norm and self._affine and x.dtype == torch.bfloat16
+                and instnorm.supported(x, norm.num_features)):
+            return instnorm.instance_norm_relu(x, norm.weight, norm.bias, norm.eps, relu=True)
+        return torch.relu_(norm(x))
 
     def forward(self, x):
-        return self._block(x)
+        if not x.is_cuda:
+            return self._block(x)
+        blk = self._block
+        x = self._norm_relu(blk[0](x), blk[1])
+        return self._norm_relu(blk[3](x), blk[4])
 
 
 class Encoder(nn.Module):

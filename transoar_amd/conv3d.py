@@ -1,0 +1,187 @@
+"""Autograd shim of the gfx950 3x3x3 convolution kernels (C ABI:
+include/transoar_conv3d.h) and an ``nn.Conv3d`` subclass that uses them.
+
+``Conv3dK3`` keeps nn.Conv3d's parameters (``weight`` (Cout,Cin,3,3,3), ``bias``)
+so checkpoints of the reference's EncoderCnnBlock / FPN output convs
+(encoder_blocks.py:28-48, attn_fpn.py:65-73) load unchanged.  On a GPU with
+bf16 activations (the autocast training path) the convolution, its data
+gradient and its weight gradient run on the hand-written implicit-GEMM
+kernels, channels-last; otherwise (CPU tests, fp32/fp64 parity runs) it is
+the stock PyTorch convolution.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _native  # noqa: F401  (torch's HIP runtime first)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
+ABI_VERSION = 1
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise _native.NativeLibraryError("%s is not built (python transoar_amd/_build.py)" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    i, p = ctypes.c_int, ctypes.c_void_p
+    lib.transoar_conv3d_k3_forward.restype = i
+    lib.transoar_conv3d_k3_forward.argtypes = [p, p, p, p] + [i] * 8 + [p]
+    lib.transoar_conv3d_k3_wgrad.restype = i
+    lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
+    lib.transoar_conv3d_c1_forward.restype = i
+    lib.transoar_conv3d_c1_forward.argtypes = [p, p, p] + [i] * 5 + [p]
+    lib.transoar_conv3d_abi_version.restype = i
+    if lib.transoar_conv3d_abi_version() != ABI_VERSION:
+        raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
+    return lib
+
+
+lib = _load()
+CL3D = torch.channels_last_3d
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _as_ndhwc(t):
+    """(N,C,D,H,W) logical -> bf16, physically NDHWC."""
+    return t.to(torch.bfloat16).contiguous(memory_format=CL3D)
+
+
+def _pack_taps(w):
+    """(Cout, Cin, 3,3,3) -> (27, Cout, Cin) bf16, tap-major."""
+    co, ci = w.shape[:2]
+    return w.permute(2, 3, 4, 0, 1).reshape(27, co, ci).to(torch.bfloat16).contiguous()
+
+
+def conv3d_k3_forward(x, wk, bias, stride, dilated_input=False):
+    """x (N,Cin,D,H,W) NDHWC bf16; wk (27,Cout,Cin) bf16 -> (N,Cout,Do,Ho,Wo) NDHWC bf16."""
+    n, ci, d, h, w = x.shape
+    co = wk.shape[1]
+    if dilated_input:
+        od, oh, ow = 2 * d, 2 * h, 2 * w
+    else:
+        od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, co, od, oh, ow), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_k3_forward(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                              y.data_ptr(), n, d, h, w, ci, co, stride, 1 if dilated_input else 0,
+                                              _stream()), "transoar_conv3d_k3_forward")
+    return y
+
+
+def wgrad_operands(x, gy, stride):
+    """Channels-first operands of the weight-gradient GEMM (K = voxels):
+    gyT (Cout,N,Do,Ho,Wo) and xT3 (3,Cin,N,D,H,Wo), the three W-shifted (and for
+    stride 2 W-decimated) copies of x."""
+    ow = gy.shape[4]
+    gy_t = gy.permute(1, 0, 2, 3, 4).contiguous()
+    x_t = F.pad(x.permute(1, 0, 2, 3, 4).contiguous(), (1, 1))             # (Cin,N,D,H,W+2), zero halo
+    x_t3 = torch.stack([x_t[..., kw: kw + stride * (ow - 1) + 1: stride] for kw in range(3)])
+    return x_t3, gy_t
+
+
+def conv3d_k3_wgrad(x, gy, stride):
+    """x (N,Cin,D,H,W), gy (N,Cout,Do,Ho,Wo) bf16 -> dW (Cout,Cin,3,3,3) fp32."""
+    n, ci, d, h, w = x.shape
+    co, od, oh, ow = gy.shape[1], gy.shape[2], gy.shape[3], gy.shape[4]
+    x_t3, gy_t = wgrad_operands(x, gy, stride)
+    cin_p = (ci + 7) // 8 * 8
+    dw = torch.zeros((27, co, cin_p), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_k3_wgrad(gy_t.data_ptr(), x_t3.data_ptr(), dw.data_ptr(), n, d, h, ow, ci,
+                                            od, oh, ow, co, stride, _stream()), "transoar_conv3d_k3_wgrad")
+    return dw[:, :, :ci].view(3, 3, 3, co, ci).permute(3, 4, 0, 1, 2)
+
+
+class _Conv3dK3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        xb = _as_ndhwc(x)
+        ci = xb.shape[1]
+        if ci == 1:
+            n, _, d, h, w = xb.shape
+            co = weight.shape[0]
+            wt = weight.float().permute(2, 3, 4, 0, 1).reshape(27, co).contiguous()
+            y = torch.empty((n, co, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
+            with torch.cuda.device(x.device):
+                _check(lib.transoar_conv3d_c1_forward(xb.data_ptr(), wt.data_ptr(), y.data_ptr(), n, d, h, w, co,
+                                                      _stream()), "transoar_conv3d_c1_forward")
+            if bias is not None:
+                y = y + bias.to(y.dtype).view(1, -1, 1, 1, 1)
+        else:
+            y = conv3d_k3_forward(xb, _pack_taps(weight), bias.float() if bias is not None else None, stride)
+        ctx.save_for_backward(xb, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    # which parts of the backward run on the hand-written kernels (measured per layer in
+    # tools/bench_conv.py, profiles/r01_conv_layers.jsonl): the stride-1 data gradient always; the
+    # dilated (stride-2) data gradient and the weight gradient only when switched on -- their v1
+    # kernels lose to MIOpen's tuned implicit GEMM, which is used through aten otherwise.
+    hip_dgrad_strided = False
+    hip_wgrad = False
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, weight = ctx.saved_tensors
+        gyb = _as_ndhwc(gy)
+        gx = gw = gb = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        hip_x = need_x and (ctx.stride == 1 or _Conv3dK3.hip_dgrad_strided)
+        hip_w = need_w and _Conv3dK3.hip_wgrad
+        if hip_x:
+            # data gradient = convolution of dy with the flipped, in/out-swapped filter
+            wt = weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, weight.shape[1], weight.shape[0])
+            gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
+        if hip_w:
+            gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
+        if (need_x and not hip_x) or (need_w and not hip_w):
+            s = ctx.stride
+            ax, aw, _ = torch.ops.aten.convolution_backward(
+                gyb, xb, weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                [need_x and not hip_x, need_w and not hip_w, False])
+            if need_x and not hip_x:
+                gx = ax
+            if need_w and not hip_w:
+                gw = aw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gyb.float().sum(dim=(0, 2, 3, 4))
+        return gx, gw, gb, None
+
+
+def hip_conv_supported(x, conv):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and (conv.in_channels % 8 == 0 or (conv.in_channels == 1 and conv.stride == (1, 1, 1)))
+            and conv.out_channels % 8 == 0 and (x.shape[-1] // conv.stride[0]) % 8 == 0
+            and (conv.stride == (1, 1, 1) or all(s % 2 == 0 for s in x.shape[2:])))
+
+
+class Conv3dK3(nn.Conv3d):
+    """nn.Conv3d(k=3, pad=1) whose bf16 GPU path is the hand-written kernel.
+    ``enabled`` is a class switch so benchmarks can A/B against MIOpen;
+    ``min_voxels``: below this many output voxels the grid is too small for the
+    v1 kernel (no split-K) and the layer stays on MIOpen."""
+    enabled = True
+    min_voxels = 1 << 20
+
+    def forward(self, x):
+        amp = torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        xb = x.to(torch.bfloat16) if (amp and x.dtype != torch.bfloat16) else x
+        if Conv3dK3.enabled and hip_conv_supported(xb, self):
+            s = self.stride[0]
+            voxels = xb.shape[0] * (xb.shape[2] // s) * (xb.shape[3] // s) * (xb.shape[4] // s)
+            if voxels >= Conv3dK3.min_voxels:
+                return _Conv3dK3.apply(xb, self.weight, self.bias, s)
+        return super().forward(x)

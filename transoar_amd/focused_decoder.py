@@ -10,11 +10,17 @@ including its quirks:
     compatibility and parity;
   * the RoI mask is built from bbox_properties[*]['attn_area'] with floor/ceil
     on a hard-coded level shape table (:99-117, :138-159).
-Host-side differences: the mask is a registered (non-persistent) buffer held as
-an additive 0/-inf tensor instead of a ``.cuda()`` attribute rewritten in place
-every call (:243-245), and the masked attention goes through
-``scaled_dot_product_attention`` so the (N, heads, Q, 102400) score tensor is
-not materialised four times per layer.
+Host-side differences (same numbers, different schedule):
+  * the mask is a registered (non-persistent) buffer instead of a ``.cuda()``
+    attribute rewritten in place every call (:243-245);
+  * the reference scores every query against all 102 400 keys and then adds
+    -inf outside the organ's box (:238-247: 145 GFLOP and a 1.77 GB fp32 score
+    tensor per layer per sample).  exp(-inf) == 0, so only the keys INSIDE the
+    box contribute: the queries of one organ share one box, so the layer
+    gathers each organ's keys/values (a fixed index list built from the mask at
+    construction) and runs a small dense attention per organ -- exactly the
+    same softmax, ~1/30 of the work, no score tensor over the whole volume.
+    The dense path remains for ``restrict_attn=False`` and ``need_weights``.
 """
 import copy
 
@@ -37,6 +43,25 @@ def _activation(name):
         raise RuntimeError("activation should be relu/gelu, not %s." % name)
 
 
+class _GatherTokens(torch.autograd.Function):
+    """x (B, S, C), index (K,) -> x[:, index].  The backward is an fp32
+    index_add_ (hardware float atomics) instead of autograd's sort-based
+    index_put_ for advanced indexing, which costs ~100x more here."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.n_tokens = x.shape[1]
+        return x.index_select(1, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        gx = torch.zeros(g.shape[0], ctx.n_tokens, g.shape[2], dtype=torch.float32, device=g.device)
+        gx.index_add_(1, index, g.float())
+        return gx.to(g.dtype), None
+
+
 class FocusedAttn(nn.Module):
     def __init__(self, dim, num_heads, attn_mask, qkv_bias=None, qk_scale=None, attn_drop=0,
                  proj_drop=0, use_pos_bias=False, return_weights=True):
@@ -57,9 +82,30 @@ class FocusedAttn(nn.Module):
         else:
             self.pos_bias = None
 
-    def forward(self, q, k, v, mask=None, need_weights=False):
-        """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf.
-        Returns (out, weights or None)."""
+    def _roi_attention(self, q, k, v, roi):
+        """Per-organ attention over the organ's own keys.  roi = (index (O,L)
+        long, pad (O,L) bool True=padding); queries are organ-major."""
+        index, pad = roi
+        b, n_q, c = q.shape
+        n_org, n_keys = index.shape
+        qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
+        flat = index.reshape(-1)
+        kk = _GatherTokens.apply(self.k_proj(k), flat).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        vv = _GatherTokens.apply(self.v_proj(v), flat).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
+        attn = qq @ kk.transpose(-2, -1)                                  # (B, O, h, qpo, L)
+        if self.pos_bias is not None:
+            attn = attn + self.pos_bias.view(n_org, qpo, -1).gather(
+                2, index[:, None, :].expand(-1, qpo, -1))[None, :, None]
+        attn = attn.masked_fill(pad[None, :, None, None, :], float("-inf")).softmax(dim=-1)
+        x = self.attn_drop(attn) @ vv                                     # (B, O, h, qpo, hd)
+        return x.permute(0, 1, 3, 2, 4).reshape(b, n_q, c)
+
+    def forward(self, q, k, v, mask=None, need_weights=False, roi=None):
+        """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf; roi: the
+        same mask as per-organ key lists.  Returns (out, weights or None)."""
+        if roi is not None and not need_weights:
+            return self.proj_drop(self.proj(self._roi_attention(q, k, v, roi))), None
         b, n_kv, c = k.shape
         n_q = q.shape[1]
         h, hd = self.num_heads, c // self.num_heads
@@ -100,6 +146,11 @@ class FocusedDecoderLayer(nn.Module):
         self.register_buffer("attn_mask", self.generate_attn_masks(), persistent=False)
         self.register_buffer("attn_bias", torch.zeros(self.attn_mask.shape).masked_fill_(
             self.attn_mask, float("-inf")), persistent=False)
+        roi = self._roi_lists()
+        self._use_roi = roi is not None
+        if roi is not None:
+            self.register_buffer("roi_index", roi[0], persistent=False)
+            self.register_buffer("roi_pad", roi[1], persistent=False)
         self.cross_attn = FocusedAttn(d_model, n_heads, self.attn_mask, proj_drop=0.1)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -133,6 +184,26 @@ class FocusedDecoderLayer(nn.Module):
             mask[q, lo[q, 0]:hi[q, 0], lo[q, 1]:hi[q, 1], lo[q, 2]:hi[q, 2]] = False
         return mask.flatten(1)
 
+    def _roi_lists(self):
+        """Key indices each organ may attend to, padded to the longest list; None
+        when the gathered form would not be smaller than the dense one."""
+        n_org, qpo = self.config["num_organs"], self.num_queries_per_organ
+        allowed = ~self.attn_mask.view(n_org, qpo, -1)
+        if not bool((allowed == allowed[:, :1]).all()):
+            return None                       # queries of an organ must share their box
+        allowed = allowed[:, 0]
+        counts = allowed.sum(1)
+        longest = int(counts.max())
+        if longest == 0 or int(counts.min()) == 0 or n_org * longest > 2 * allowed.shape[1]:
+            return None
+        index = torch.zeros(n_org, longest, dtype=torch.long)
+        pad = torch.ones(n_org, longest, dtype=torch.bool)
+        for o in range(n_org):
+            ids = allowed[o].nonzero().flatten()
+            index[o, : ids.numel()] = ids
+            pad[o, : ids.numel()] = False
+        return index, pad
+
     def forward(self, tgt, query_pos, src_pos, src, need_weights=False):
         q = k = tgt if query_pos is None else tgt + query_pos
         sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
@@ -141,7 +212,8 @@ class FocusedDecoderLayer(nn.Module):
 
         q = tgt if query_pos is None else tgt + query_pos
         k = src if src_pos is None else src + src_pos
-        ca, weights = self.cross_attn(q, k, src, mask=self.attn_bias, need_weights=need_weights)
+        roi = (self.roi_index, self.roi_pad) if self._use_roi else None
+        ca, weights = self.cross_attn(q, k, src, mask=self.attn_bias, need_weights=need_weights, roi=roi)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
         ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
