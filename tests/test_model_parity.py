@@ -128,7 +128,10 @@ def test_g6_backbone(golden_dir, debug_core, device, tag, refine):
     grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
     for name, g, s, a in zip(params, grads, z[tag + ".grad_sums"], z[tag + ".grad_abs_sums"]):
         got = 0.0 if g is None else g.double().sum().item()
-        assert abs(got - s) <= 2e-4 * max(a, 1e-6) + 1e-7, name
+        # checksums of fp32 gradients through 12 InstanceNorm layers are ill-conditioned (see
+        # tests/test_data_parallel.py): 2e-4 of sum|g| CPU-vs-CPU, 5e-3 CPU golden vs GPU kernels
+        tol = 2e-4 if device == "cpu" else 5e-3
+        assert abs(got - s) <= tol * max(a, 1e-6) + 1e-7, name
 
 
 @pytest.mark.parametrize("device", _device_params())
@@ -170,6 +173,6 @@ def test_g7_whole_model_and_criterion(golden_dir, debug_core, device, tag, refin
     for name, g, s, a in zip(params, grads, z[tag + ".grad_sums"], z[tag + ".grad_abs_sums"]):
         if g is None:
             continue
-        if abs(g.double().sum().item() - s) > 1e-3 * max(a, 1e-6) + 1e-7:
+        if abs(g.double().sum().item() - s) > (1e-3 if device == "cpu" else 5e-2) * max(a, 1e-6) + 1e-7:
             bad.append((name, g.double().sum().item(), s, a))
     assert not bad, bad[:5]

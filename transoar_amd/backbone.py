@@ -130,7 +130,9 @@ class Decoder(nn.Module):
                 use_cuda=config["use_cuda"])
 
     def forward(self, x):
-        feats = list(x.values())[-self._lateral_levels:]
+        # the encoder hands over channels-last (NDHWC) bf16 maps on the GPU; everything from here
+        # on is a torch/MIOpen convolution whose tuned kernels are keyed on NCDHW (miopen_db/)
+        feats = [f.contiguous() for f in list(x.values())[-self._lateral_levels:]]
         laterals = [conv(f) for conv, f in zip(self._lateral, feats)]
         # merged[s - first] = lateral_s + up(merged_{s+1})
         merged = [None] * self._lateral_levels

@@ -107,7 +107,9 @@ def conv3d_k3_wgrad(x, gy, stride):
 class _Conv3dK3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
-        xb = _as_ndhwc(x)
+        # one input channel: NDHWC == NCDHW; keep canonical strides so nothing downstream
+        # (MIOpen's weight gradient) mistakes it for a channels-last problem
+        xb = x.to(torch.bfloat16).contiguous() if x.shape[1] == 1 else _as_ndhwc(x)
         ci = xb.shape[1]
         if ci == 1:
             n, _, d, h, w = xb.shape
@@ -148,8 +150,10 @@ class _Conv3dK3(torch.autograd.Function):
             gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
         if (need_x and not hip_x) or (need_w and not hip_w):
             s = ctx.stride
+            # NCDHW-contiguous operands: that is the layout the tuned MIOpen find-db entries
+            # (miopen_db/) are keyed on; an NDHWC problem would fall back to MIOpen's naive kernels
             ax, aw, _ = torch.ops.aten.convolution_backward(
-                gyb, xb, weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                gyb.contiguous(), xb.contiguous(), weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
                 [need_x and not hip_x, need_w and not hip_w, False])
             if need_x and not hip_x:
                 gx = ax
@@ -184,4 +188,5 @@ class Conv3dK3(nn.Conv3d):
             voxels = xb.shape[0] * (xb.shape[2] // s) * (xb.shape[3] // s) * (xb.shape[4] // s)
             if voxels >= Conv3dK3.min_voxels:
                 return _Conv3dK3.apply(xb, self.weight, self.bias, s)
-        return super().forward(x)
+        # stock convolution (MIOpen on the GPU): NCDHW-contiguous input, see the note in backward
+        return super().forward(x.contiguous() if x.is_cuda else x)
