@@ -69,6 +69,14 @@ int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N,
 int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H,
                                int W, int Cout, void* hip_stream);
 
+/*
+ * bf16 layout change between channels-last (N, V, C) and channels-first
+ * (N, C, V), V = D*H*W, C % 8 == 0.  to_channels_first != 0: in is (N,V,C).
+ * Used where a hand-written (NDHWC) layer meets a torch/MIOpen (NCDHW) one.
+ */
+int transoar_layout_bf16(const void* in, void* out, int N, long V, int C, int to_channels_first,
+                         void* hip_stream);
+
 int transoar_conv3d_abi_version(void);
 
 #ifdef __cplusplus

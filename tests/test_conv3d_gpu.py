@@ -49,3 +49,14 @@ def test_conv3d_k3_forward_backward(case):
         assert relerr(conv.bias.grad, br.grad) <= 2e-3
     if ci != 1:
         assert relerr(x.grad, xr.grad) <= 2.0 ** -7
+
+
+def test_layout_kernels_roundtrip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd.conv3d import to_ncdhw, to_ndhwc
+    x = torch.randn(2, 24, 3, 5, 8, device="cuda").to(torch.bfloat16)
+    cl = to_ndhwc(x)
+    assert cl.is_contiguous(memory_format=torch.channels_last_3d) and torch.equal(cl, x)
+    back = to_ncdhw(cl)
+    assert back.is_contiguous() and torch.equal(back, x)

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from . import instnorm
-from .conv3d import Conv3dK3
+from .conv3d import Conv3dK3, to_ncdhw
 from .position_encoding import PositionEmbeddingLearned3D, PositionEmbeddingSine3D
 from .refine_block import DecoderDefAttnBlock
 
@@ -132,7 +132,7 @@ class Decoder(nn.Module):
     def forward(self, x):
         # the encoder hands over channels-last (NDHWC) bf16 maps on the GPU; everything from here
         # on is a torch/MIOpen convolution whose tuned kernels are keyed on NCDHW (miopen_db/)
-        feats = [f.contiguous() for f in list(x.values())[-self._lateral_levels:]]
+        feats = [to_ncdhw(f) for f in list(x.values())[-self._lateral_levels:]]
         laterals = [conv(f) for conv, f in zip(self._lateral, feats)]
         # merged[s - first] = lateral_s + up(merged_{s+1})
         merged = [None] * self._lateral_levels

@@ -20,7 +20,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def _load():
@@ -34,6 +34,8 @@ def _load():
     lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
     lib.transoar_conv3d_c1_forward.argtypes = [p, p, p] + [i] * 5 + [p]
+    lib.transoar_layout_bf16.restype = i
+    lib.transoar_layout_bf16.argtypes = [p, p, i, ctypes.c_long, i, i, p]
     lib.transoar_conv3d_abi_version.restype = i
     if lib.transoar_conv3d_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -53,9 +55,37 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _as_ndhwc(t):
-    """(N,C,D,H,W) logical -> bf16, physically NDHWC."""
-    return t.to(torch.bfloat16).contiguous(memory_format=CL3D)
+def _relayout(t, to_channels_first):
+    n, c = t.shape[:2]
+    v = t.shape[2] * t.shape[3] * t.shape[4]
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device,
+                      memory_format=torch.contiguous_format if to_channels_first else CL3D)
+    with torch.cuda.device(t.device):
+        _check(lib.transoar_layout_bf16(t.data_ptr(), out.data_ptr(), n, v, c, 1 if to_channels_first else 0,
+                                        _stream()), "transoar_layout_bf16")
+    return out
+
+
+def to_ndhwc(t):
+    """(N,C,D,H,W) logical -> bf16, physically NDHWC (channels_last_3d)."""
+    t = t.to(torch.bfloat16)
+    if t.is_contiguous(memory_format=CL3D):
+        return t
+    if t.is_cuda and t.is_contiguous() and t.shape[1] % 8 == 0:
+        return _relayout(t, False)
+    return t.contiguous(memory_format=CL3D)
+
+
+def to_ncdhw(t):
+    """physically NCDHW copy (or the tensor itself when it already is)."""
+    if t.is_contiguous():
+        return t
+    if t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(memory_format=CL3D) and t.shape[1] % 8 == 0:
+        return _relayout(t, True)
+    return t.contiguous()
+
+
+_as_ndhwc = to_ndhwc
 
 
 def _pack_taps(w):
@@ -153,7 +183,7 @@ class _Conv3dK3(torch.autograd.Function):
             # NCDHW-contiguous operands: that is the layout the tuned MIOpen find-db entries
             # (miopen_db/) are keyed on; an NDHWC problem would fall back to MIOpen's naive kernels
             ax, aw, _ = torch.ops.aten.convolution_backward(
-                gyb.contiguous(), xb.contiguous(), weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                to_ncdhw(gyb), to_ncdhw(xb), weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
                 [need_x and not hip_x, need_w and not hip_w, False])
             if need_x and not hip_x:
                 gx = ax
@@ -189,4 +219,4 @@ class Conv3dK3(nn.Conv3d):
             if voxels >= Conv3dK3.min_voxels:
                 return _Conv3dK3.apply(xb, self.weight, self.bias, s)
         # stock convolution (MIOpen on the GPU): NCDHW-contiguous input, see the note in backward
-        return super().forward(x.contiguous() if x.is_cuda else x)
+        return super().forward(to_ncdhw(x) if x.is_cuda else x)

@@ -361,6 +361,47 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// layout changes between channels-last (N, V, C) and channels-first (N, C, V),
+// bf16.  One thread per voxel: 16-byte accesses on the channels-last side
+// (8 channels of its voxel), 2-byte accesses coalesced across the wave on the
+// channels-first side.  (torch's generic strided copy does the same job at
+// ~100 GB/s; these run near HBM speed.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layout_vc_to_cv(const unsigned short* __restrict__ in,
+                                                        unsigned short* __restrict__ out, long V, int C) {
+  const long v = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (v >= V) return;
+  const long n = blockIdx.y;
+  const unsigned short* src = in + (n * V + v) * C;
+  unsigned short* dst = out + n * C * V + v;
+  for (int c = 0; c < C; c += 8) {
+    const u32x4c r = *reinterpret_cast<const u32x4c*>(src + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[static_cast<long>(c + 2 * e) * V] = static_cast<unsigned short>(r[e] & 0xffffu);
+      dst[static_cast<long>(c + 2 * e + 1) * V] = static_cast<unsigned short>(r[e] >> 16);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layout_cv_to_vc(const unsigned short* __restrict__ in,
+                                                        unsigned short* __restrict__ out, long V, int C) {
+  const long v = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (v >= V) return;
+  const long n = blockIdx.y;
+  const unsigned short* src = in + n * C * V + v;
+  unsigned short* dst = out + (n * V + v) * C;
+  for (int c = 0; c < C; c += 8) {
+    u32x4c r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      r[e] = static_cast<unsigned>(src[static_cast<long>(c + 2 * e) * V]) |
+             (static_cast<unsigned>(src[static_cast<long>(c + 2 * e + 1) * V]) << 16);
+    *reinterpret_cast<u32x4c*>(dst + c) = r;
+  }
+}
+
 static inline bool fits32(long bytes) { return bytes > 0 && bytes < 0xfffffff0L; }
 
 }  // namespace transoar
@@ -446,4 +487,20 @@ extern "C" int transoar_conv3d_c1_forward(const void* x, const float* w, void* y
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_conv3d_abi_version(void) { return 1; }
+extern "C" int transoar_layout_bf16(const void* in, void* out, int N, long V, int C, int to_channels_first,
+                                    void* hip_stream) {
+  if (!in || !out) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || V <= 0 || C <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (C & 7) return TRANSOAR_CONV_ERR_CHANNELS;
+  const dim3 grid(static_cast<unsigned>((V + 255) / 256), static_cast<unsigned>(N));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (to_channels_first)
+    hipLaunchKernelGGL(layout_vc_to_cv, grid, dim3(256), 0, st, static_cast<const unsigned short*>(in),
+                       static_cast<unsigned short*>(out), V, C);
+  else
+    hipLaunchKernelGGL(layout_cv_to_vc, grid, dim3(256), 0, st, static_cast<const unsigned short*>(in),
+                       static_cast<unsigned short*>(out), V, C);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_abi_version(void) { return 2; }

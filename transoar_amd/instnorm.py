@@ -6,6 +6,7 @@ import os
 import torch
 
 from . import _native  # noqa: F401
+from .conv3d import to_ndhwc
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_instnorm.so")
@@ -38,7 +39,7 @@ def supported(x, channels):
 class _InstNormReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu):
-        x = x.contiguous(memory_format=CL3D)
+        x = to_ndhwc(x)
         n, c = x.shape[:2]
         v = x.shape[2] * x.shape[3] * x.shape[4]
         y = torch.empty_like(x, memory_format=CL3D)
@@ -58,7 +59,7 @@ class _InstNormReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, g32, b32, mean_rstd = ctx.saved_tensors
-        dy = dy.to(torch.bfloat16).contiguous(memory_format=CL3D)
+        dy = to_ndhwc(dy)
         n, c = x.shape[:2]
         v = x.shape[2] * x.shape[3] * x.shape[4]
         dx = torch.empty_like(x, memory_format=CL3D)
