@@ -79,6 +79,11 @@ enum {
  * loc_dtype   : dtype of sampling_loc and attn_weight; must equal value_dtype,
  *               or be TRANSOAR_F32 when value_dtype is BF16/F16 (the layout
  *               bf16 autocast produces).
+ * host_spatial_shapes: optional HOST copy of spatial_shapes (L*3 int64) or
+ *               NULL.  The reference passes the shapes as a device tensor only;
+ *               when the host also knows them the kernels walk the work in
+ *               4x4x8-voxel bricks for L2 locality.  A schedule hint: results
+ *               are identical with NULL.
  * Replaces ms_deform_attn_forward (ops/src/ms_deform_attn.h:20-39).
  */
 int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
@@ -86,7 +91,8 @@ int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
                             const void* sampling_loc, const void* attn_weight,
                             void* out, int N, int S, int M, int C, int L,
                             int Lq, int P, int value_dtype, int loc_dtype,
-                            unsigned flags, void* hip_stream);
+                            const int64_t* host_spatial_shapes, unsigned flags,
+                            void* hip_stream);
 
 /*
  * Backward.  Writes grad_value (shape and dtype of value), grad_sampling_loc
@@ -108,7 +114,8 @@ int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
                              void* grad_sampling_loc, void* grad_attn_weight,
                              void* workspace, size_t workspace_bytes,
                              int N, int S, int M, int C, int L, int Lq, int P,
-                             int value_dtype, int loc_dtype, unsigned flags,
+                             int value_dtype, int loc_dtype,
+                             const int64_t* host_spatial_shapes, unsigned flags,
                              void* hip_stream);
 
 /* Scratch bytes transoar_msda3d_backward needs (0 if the arguments are

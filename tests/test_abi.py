@@ -37,17 +37,17 @@ def test_argument_errors_are_returned_not_printed():
     p16 = (p + 15) & ~15
     dims_ok = (1, 8, 1, 4, 1, 1, 1)
     # NULL pointer
-    assert lib.transoar_msda3d_forward(None, p16, p16, p16, p16, p16, *dims_ok, 0, 0, 0, None) == -1
+    assert lib.transoar_msda3d_forward(None, p16, p16, p16, p16, p16, *dims_ok, 0, 0, None, 0, None) == -1
     # bad dimension
-    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 0, 1, 1, 1, 0, 0, 0, None) == -2
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 0, 1, 1, 1, 0, 0, None, 0, None) == -2
     # dtype combination: f32 value with f64 loc
-    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, *dims_ok, 0, 1, 0, None) == -3
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, *dims_ok, 0, 1, None, 0, None) == -3
     # bf16 value with fp32 loc is legal as far as dtype goes; misaligned buffer
-    assert lib.transoar_msda3d_forward(p16 + 4, p16, p16, p16, p16, p16, *dims_ok, 2, 0, 0, None) == -4
+    assert lib.transoar_msda3d_forward(p16 + 4, p16, p16, p16, p16, p16, *dims_ok, 2, 0, None, 0, None) == -4
     # too many levels
-    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 4, 9, 1, 1, 0, 0, 0, None) == -5
-    assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, None, p16, p16, p16, None, 0, *dims_ok, 0, 0, 0, None) == -1
-    assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, p16, p16, p16, p16, None, 0, 2, 1000, 6, 64, 1, 10, 4, 0, 0, 0, None) == -6
+    assert lib.transoar_msda3d_forward(p16, p16, p16, p16, p16, p16, 1, 8, 1, 4, 9, 1, 1, 0, 0, None, 0, None) == -5
+    assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, None, p16, p16, p16, None, 0, *dims_ok, 0, 0, None, 0, None) == -1
+    assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, p16, p16, p16, p16, None, 0, 2, 1000, 6, 64, 1, 10, 4, 0, 0, None, 0, None) == -6
     assert lib.transoar_msda3d_backward_workspace_bytes(2, 1000, 6, 64, 1, 10, 4, 0, 0, 0) > 0
     for code in (0, -1, -2, -3, -4, -5, -6):
         assert len(lib.transoar_msda3d_strerror(code)) > 0

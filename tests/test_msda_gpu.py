@@ -274,3 +274,20 @@ def test_flagship_backward_mass_conservation(MSDA, flagship):
     rgl, rga = torch.autograd.grad(ref, (lc, ac), go[:, pick].cpu())
     assert relerr(gl[:, pick], rgl) <= 1e-4
     assert relerr(ga[:, pick], rga) <= 1e-4
+
+
+def test_brick_schedule_is_only_a_schedule(MSDA):
+    """The optional host copy of the level shapes reorders the work (4x4x8
+    bricks); outputs must not depend on it.  Odd extents exercise the padding."""
+    levels = [(5, 6, 9), (3, 3, 5), (1, 2, 3)]
+    value, shapes, lsi, loc, attn = _inputs.model_like_inputs(3, 2, levels, device="cuda")
+    go = torch.randn(2, loc.shape[1], 6 * 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    res = {}
+    for hint in (True, False):
+        MSDA.locality_hint = hint
+        res[hint] = (MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64),
+                     *MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 64))
+    MSDA.locality_hint = True
+    assert torch.equal(res[True][0], res[False][0])          # forward: same arithmetic per item
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert relerr(a, b) <= 1e-5

@@ -18,7 +18,7 @@ _LIB_NAME = "libtransoar_msda3d.so"
 
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FORCE_GENERIC = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NativeLibraryError(ImportError):
@@ -36,10 +36,10 @@ def _load():
     c_int, c_void_p, c_uint = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint
     try:
         lib.transoar_msda3d_forward.restype = c_int
-        lib.transoar_msda3d_forward.argtypes = [c_void_p] * 6 + [c_int] * 9 + [c_uint, c_void_p]
+        lib.transoar_msda3d_forward.argtypes = [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_uint, c_void_p]
         lib.transoar_msda3d_backward.restype = c_int
         lib.transoar_msda3d_backward.argtypes = ([c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 9 +
-                                                 [c_uint, c_void_p])
+                                                 [c_void_p, c_uint, c_void_p])
         lib.transoar_msda3d_backward_workspace_bytes.restype = ctypes.c_size_t
         lib.transoar_msda3d_backward_workspace_bytes.argtypes = [c_int] * 9 + [c_uint]
         lib.transoar_msda3d_profile_enable.restype = None

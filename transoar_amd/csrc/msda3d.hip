@@ -69,6 +69,34 @@ static inline int lpv_log2(int C, int elt) {
   return -1;
 }
 
+// Brick schedule from host-side level shapes (NULL -> linear order).  `rows` is what the
+// kernel's row index ranges over (S for voxel rows; Lq for queries, usable only when Lq == S,
+// i.e. the queries ARE the pyramid's voxels as in the refine block's self-attention).
+static BrickOrder make_order(const int64_t* host_shapes, const Dims& d, int rows) {
+  BrickOrder o{};
+  if (!host_shapes || rows != d.S) return o;
+  long start = 0, pad = 0;
+  for (int l = 0; l < d.L; ++l) {
+    const long D = host_shapes[3 * l], H = host_shapes[3 * l + 1], W = host_shapes[3 * l + 2];
+    if (D <= 0 || H <= 0 || W <= 0) return BrickOrder{};
+    o.D[l] = static_cast<int>(D); o.H[l] = static_cast<int>(H); o.W[l] = static_cast<int>(W);
+    o.start[l] = static_cast<int>(start);
+    o.nbh[l] = static_cast<int>((H + kBrickH - 1) / kBrickH);
+    o.nbw[l] = static_cast<int>((W + kBrickW - 1) / kBrickW);
+    o.pad_start[l] = static_cast<int>(pad);
+    pad += ((D + kBrickD - 1) / kBrickD) * o.nbh[l] * o.nbw[l] * kBrickSlots;
+    start += D * H * W;
+  }
+  if (start != d.S || pad * d.N * d.M >= (1L << 31)) return BrickOrder{};
+  o.pad_start[d.L] = static_cast<int>(pad);
+  o.L = d.L;
+  o.enabled = 1;
+  return o;
+}
+static inline long order_units(const BrickOrder& o, const Dims& d, int rows) {
+  return static_cast<long>(d.N) * d.M * (o.enabled ? o.pad_start[o.L] : rows);
+}
+
 static inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
 
 // Can the vector kernels run this problem?  (32-bit byte offsets into value,
@@ -106,9 +134,11 @@ static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
 template <typename VT, typename LT>
 static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, void* out, const Dims& d,
-                      unsigned flags, hipStream_t st) {
+                      const int64_t* host_shapes, unsigned flags, hipStream_t st) {
   const long n_items = static_cast<long>(d.N) * d.Lq * d.M;
-  const long n_blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  const BrickOrder order = make_order(host_shapes, d, d.Lq);
+  const long n_units = order_units(order, d, d.Lq);
+  const long n_blocks = ((order.enabled ? n_units : n_items) + kWavesPerBlock - 1) / kWavesPerBlock;
   const int lg = vec_lpv(d, sizeof(VT), flags);
   const dim3 block(64 * kWavesPerBlock);
   auto v = static_cast<const VT*>(value);
@@ -117,15 +147,15 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
   auto o = static_cast<VT*>(out);
   if (lg < 0) {
     ProfScope prof(TRANSOAR_PROF_FWD_GENERIC, st);
-    hipLaunchKernelGGL((msda3d_fwd_generic<VT, LT>), dim3(n_blocks), block, 0, st, v, shapes, lsi,
-                       lo, at, o, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
+    hipLaunchKernelGGL((msda3d_fwd_generic<VT, LT>), dim3((n_items + kWavesPerBlock - 1) / kWavesPerBlock),
+                       block, 0, st, v, shapes, lsi, lo, at, o, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
   } else {
     ProfScope prof(TRANSOAR_PROF_FWD, st);
     const dim3 grid(((n_blocks + 7) / 8) * 8);
     const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
 #define TRANSOAR_FWD(LG)                                                                      \
   hipLaunchKernelGGL((msda3d_fwd_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, at, \
-                     o, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_items, n_blocks)
+                     o, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_units, n_blocks, order)
     if (lg == 3) TRANSOAR_FWD(3);
     else if (lg == 4) TRANSOAR_FWD(4);
     else TRANSOAR_FWD(5);
@@ -152,11 +182,13 @@ template <typename VT, typename LT>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* grad_value,
                       void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes,
-                      const Dims& d, unsigned flags, hipStream_t st) {
+                      const Dims& d, const int64_t* host_shapes, unsigned flags, hipStream_t st) {
   using A = typename Elem<VT>::acc;
   if (workspace_bytes < bwd_workspace_bytes<VT, LT>(d, flags)) return TRANSOAR_ERR_WORKSPACE;
   const long n_items = static_cast<long>(d.N) * d.Lq * d.M;
-  const long n_blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  const BrickOrder q_order = make_order(host_shapes, d, d.Lq);
+  const long q_units = order_units(q_order, d, d.Lq);
+  const long n_blocks = (q_units + kWavesPerBlock - 1) / kWavesPerBlock;
   const int lg = vec_lpv(d, sizeof(VT), flags);
   const dim3 block(64 * kWavesPerBlock);
   auto v = static_cast<const VT*>(value);
@@ -172,8 +204,9 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
     ProfScope prof(TRANSOAR_PROF_BWD_GENERIC, st);
     A* gv = sizeof(VT) == 2 ? static_cast<A*>(workspace) : static_cast<A*>(grad_value);
     TRANSOAR_CHECK_HIP(hipMemsetAsync(gv, 0, sizeof(A) * value_elems, st));
-    hipLaunchKernelGGL((msda3d_bwd_generic<VT, LT>), dim3(n_blocks), block, 0, st, v, shapes, lsi,
-                       lo, at, go, gv, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, n_items);
+    hipLaunchKernelGGL((msda3d_bwd_generic<VT, LT>), dim3((n_items + kWavesPerBlock - 1) / kWavesPerBlock),
+                       block, 0, st, v, shapes, lsi, lo, at, go, gv, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P,
+                       n_items);
     if (sizeof(VT) == 2) {
       const int cast_blocks = static_cast<int>(std::min<size_t>((value_elems + 255) / 256, 1 << 16));
       hipLaunchKernelGGL((msda3d_cast_rows<VT>), dim3(cast_blocks), dim3(256), 0, st,
@@ -188,7 +221,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   // 1. grad_loc / grad_attn
 #define TRANSOAR_BWDQ(LG)                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
-                     at, go, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, n_items, n_blocks)
+                     at, go, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
   {
     ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
     if (lg == 3) TRANSOAR_BWDQ(3);
@@ -228,12 +261,13 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   }
 
   // 3. grad_value rows
-  const long n_rows = static_cast<long>(d.N) * d.S * d.M;
+  const BrickOrder r_order = make_order(host_shapes, d, d.S);
+  const long n_rows = order_units(r_order, d, d.S);
   const long r_blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
   const dim3 rgrid(((r_blocks + 7) / 8) * 8);
 #define TRANSOAR_PULL(LG)                                                                        \
   hipLaunchKernelGGL((msda3d_bwd_value_pull<VT, A, LG>), rgrid, block, 0, st, go, shapes, lsi, count, \
-                     recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks)
+                     recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks, r_order)
   {
     ProfScope prof(TRANSOAR_PROF_PULL, st);
     if (lg == 3) TRANSOAR_PULL(3);
@@ -277,7 +311,8 @@ extern "C" int transoar_msda3d_forward(const void* value, const int64_t* spatial
                                        const int64_t* level_start_index, const void* sampling_loc,
                                        const void* attn_weight, void* out, int N, int S, int M,
                                        int C, int L, int Lq, int P, int value_dtype, int loc_dtype,
-                                       unsigned flags, void* hip_stream) {
+                                       const int64_t* host_spatial_shapes, unsigned flags,
+                                       void* hip_stream) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out)
     return TRANSOAR_ERR_NULL;
   const Dims d{N, S, M, C, L, Lq, P};
@@ -288,7 +323,7 @@ extern "C" int transoar_msda3d_forward(const void* value, const int64_t* spatial
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   TRANSOAR_DISPATCH(value_dtype, loc_dtype,
                     (launch_fwd<VT, LT>(value, spatial_shapes, level_start_index, sampling_loc,
-                                        attn_weight, out, d, flags, st)));
+                                        attn_weight, out, d, host_spatial_shapes, flags, st)));
 }
 
 extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
@@ -298,7 +333,8 @@ extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatia
                                         void* grad_attn_weight, void* workspace,
                                         size_t workspace_bytes, int N, int S, int M, int C, int L,
                                         int Lq, int P, int value_dtype, int loc_dtype,
-                                        unsigned flags, void* hip_stream) {
+                                        const int64_t* host_spatial_shapes, unsigned flags,
+                                        void* hip_stream) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight ||
       !grad_out || !grad_value || !grad_sampling_loc || !grad_attn_weight)
     return TRANSOAR_ERR_NULL;
@@ -314,7 +350,8 @@ extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatia
   TRANSOAR_DISPATCH(value_dtype, loc_dtype,
                     (launch_bwd<VT, LT>(value, spatial_shapes, level_start_index, sampling_loc,
                                         attn_weight, grad_out, grad_value, grad_sampling_loc,
-                                        grad_attn_weight, workspace, workspace_bytes, d, flags, st)));
+                                        grad_attn_weight, workspace, workspace_bytes, d,
+                                        host_spatial_shapes, flags, st)));
 }
 
 extern "C" size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C, int L, int Lq,
@@ -367,4 +404,4 @@ extern "C" int transoar_msda3d_profile_read(double* total_ms, long* launches) {
   return rc;
 }
 
-extern "C" int transoar_msda3d_abi_version(void) { return 3; }
+extern "C" int transoar_msda3d_abi_version(void) { return 4; }

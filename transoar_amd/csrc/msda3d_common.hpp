@@ -185,6 +185,46 @@ __device__ __forceinline__ A sum_transpose64(const A (&v)[64], int lane) {
   return a1[0];
 }
 
+// Work ordering.  Waves that run close together in time should touch
+// neighbouring voxels in all three axes, so that the 8-corner / 8-cell
+// footprints they share are still in L2 (4 MiB per XCD): linear (d,h,w) order
+// only gives reuse along w and h; a d-neighbour is 15 000 waves away.  When the
+// host knows the level shapes, work is therefore walked in 4x4x8-voxel bricks
+// (128 slots per brick, padded at the level borders).  Purely a schedule:
+// results do not depend on it.
+constexpr int kBrickD = 4, kBrickH = 4, kBrickW = 8, kBrickSlots = 128;
+struct BrickOrder {
+  int enabled, L;
+  int D[8], H[8], W[8], start[8];
+  int nbh[8], nbw[8];
+  int pad_start[9];       // first padded slot of each level, pad_start[L] = total
+};
+// padded slot -> voxel row of the pyramid, or -1 for a padding slot (x wave-uniform)
+__device__ __forceinline__ int brick_slot_to_row(const BrickOrder& o, int x) {
+  int l = 0;
+  for (int t = 1; t < o.L; ++t) l += (x >= o.pad_start[t]) ? 1 : 0;
+  const int local = x - o.pad_start[l];
+  const int brick = local >> 7, slot = local & 127;
+  const int bw = brick % o.nbw[l];
+  const int r = brick / o.nbw[l];
+  const int bh = r % o.nbh[l], bd = r / o.nbh[l];
+  const int d = bd * kBrickD + (slot >> 5), h = bh * kBrickH + ((slot >> 3) & 3), w = bw * kBrickW + (slot & 7);
+  if (d >= o.D[l] || h >= o.H[l] || w >= o.W[l]) return -1;
+  return o.start[l] + (d * o.H[l] + h) * o.W[l] + w;
+}
+// work unit u of a (batch, row-or-query, head) decomposition -> flat (b*R + r)*M + m, or -1.
+// R = rows per batch element (S or Lq).
+__device__ __forceinline__ long ordered_unit(const BrickOrder& o, long u, int R, int M) {
+  if (!o.enabled) return u;
+  const int m = static_cast<int>(u % M);
+  const long t = u / M;
+  const int total = o.pad_start[o.L];
+  const int x = static_cast<int>(t % total);
+  const long b = t / total;
+  const int r = brick_slot_to_row(o, x);
+  return r < 0 ? -1 : (b * R + r) * M + m;
+}
+
 // Observed (not contractual) placement: block b runs on XCD b % 8.  Remap so
 // each XCD walks one contiguous eighth of the work and neighbouring query
 // blocks share that XCD's L2.  Returns -1 for the padding blocks.

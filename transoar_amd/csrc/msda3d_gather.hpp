@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_vec(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
     const LT* __restrict__ attn, VT* __restrict__ out, int S, int M, int C,
-    int L, int Lq, int P, unsigned value_bytes, long n_items, long n_blocks) {
+    int L, int Lq, int P, unsigned value_bytes, long n_units, long n_blocks, BrickOrder order) {
   using A = typename Elem<VT>::acc;
   constexpr int VEC = Elem<VT>::VEC;
   constexpr int LPV = 1 << LOG2_LPV;   // lanes per voxel row
@@ -90,9 +90,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_vec(
   const long blk = xcd_contiguous_block(blockIdx.x, n_blocks);
   if (blk < 0) return;
   const int lane = threadIdx.x & 63;
-  const long item = __builtin_amdgcn_readfirstlane(
+  const long unit = __builtin_amdgcn_readfirstlane(
       static_cast<int>(blk * kWavesPerBlock + (threadIdx.x >> 6)));
-  if (item >= n_items) return;
+  if (unit >= n_units) return;
+  const long item = ordered_unit(order, unit, Lq, M);
+  if (item < 0) return;
   const int m = static_cast<int>(item % M);
   const long b = (item / M) / Lq;
   const int cv = lane & (LPV - 1);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
     const LT* __restrict__ attn, const VT* __restrict__ grad_out,
     LT* __restrict__ grad_loc, LT* __restrict__ grad_attn, int S, int M, int C,
-    int L, int Lq, int P, unsigned value_bytes, long n_items, long n_blocks) {
+    int L, int Lq, int P, unsigned value_bytes, long n_units, long n_blocks, BrickOrder order) {
   using A = typename Elem<VT>::acc;
   constexpr int VEC = Elem<VT>::VEC;
   constexpr int LPV = 1 << LOG2_LPV;
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
   const long blk = xcd_contiguous_block(blockIdx.x, n_blocks);
   if (blk < 0) return;
   const int lane = threadIdx.x & 63;
-  const long item = __builtin_amdgcn_readfirstlane(
+  const long unit = __builtin_amdgcn_readfirstlane(
       static_cast<int>(blk * kWavesPerBlock + (threadIdx.x >> 6)));
-  if (item >= n_items) return;
+  if (unit >= n_units) return;
+  const long item = ordered_unit(order, unit, Lq, M);
+  if (item < 0) return;
   const int m = static_cast<int>(item % M);
   const long b = (item / M) / Lq;
   const int cv = lane & (LPV - 1);

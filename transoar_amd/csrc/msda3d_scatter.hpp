@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_value_pull(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const int* __restrict__ offset,
     const PointRec<A>* __restrict__ recs, const int* __restrict__ rec_item,
-    VT* __restrict__ grad_value, int S, int M, int C, int L, long n_rows, long n_blocks) {
+    VT* __restrict__ grad_value, int S, int M, int C, int L, long n_units, long n_blocks,
+    BrickOrder order) {
   constexpr int VEC = Elem<VT>::VEC;
   constexpr int LPV = 1 << LOG2_LPV;
   constexpr int CPI = 64 / LPV;   // records handled per load instruction
@@ -196,9 +197,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_value_pull(
   const long blk = xcd_contiguous_block(blockIdx.x, n_blocks);
   if (blk < 0) return;
   const int lane = threadIdx.x & 63;
-  const long row = __builtin_amdgcn_readfirstlane(
+  const long unit = __builtin_amdgcn_readfirstlane(
       static_cast<int>(blk * kWavesPerBlock + (threadIdx.x >> 6)));
-  if (row >= n_rows) return;
+  if (unit >= n_units) return;
+  const long row = ordered_unit(order, unit, S, M);
+  if (row < 0) return;
   const int m = static_cast<int>(row % M);
   const int bs = static_cast<int>(row / M);
   const int b = bs / S, s = bs - b * S;
@@ -219,21 +222,51 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_value_pull(
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = A(0);
 
+  // This voxel is corner k = (dd,dh,dw) of every point binned in cell (voxel - k).  The 8 record
+  // lists are walked as ONE flattened sequence i = 0..total, CPI lane groups taking every CPI-th
+  // record, so that the record/item loads of step i+CPI are in flight while step i's grad_out row
+  // is being fetched (the dependent chain per step is one memory latency, not two).
+  int beg[8], pre[9];
+  pre[0] = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    // this voxel is corner k (dd,dh,dw) of every point binned in cell voxel-k
     const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
     const int bin = bin0 + ((d - dd + 1) * (g.H + 1) + (h - dh + 1)) * (g.W + 1) + (w - dw + 1);
-    const int beg = offset[bin], end = offset[bin + 1];
-    for (int t = beg + cg; t < end; t += CPI) {
-      const PointRec<A> r = recs[t];
-      const long item = rec_item[t];
-      A go[VEC];
-      Elem<VT>::unpack(*reinterpret_cast<const u32x4*>(grad_out + item * C + cv * VEC), go);
-      const A wt = (dd ? r.ld : A(1) - r.ld) * (dh ? r.lh : A(1) - r.lh) * (dw ? r.lw : A(1) - r.lw) * r.a;
+    beg[k] = offset[bin];
+    pre[k + 1] = pre[k] + (offset[bin + 1] - beg[k]);
+  }
+  const int total = pre[8];
+  auto locate = [&](int i, int& k, int& t) {
+    k = 0;
+    t = i + beg[0];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] += wt * go[e];
+    for (int j = 1; j < 8; ++j)
+      if (i >= pre[j]) { k = j; t = i - pre[j] + beg[j]; }
+  };
+
+  int i = cg, k_next = 0, t_next = 0, item_next = 0;
+  PointRec<A> r_next{A(0), A(0), A(0), A(0)};
+  if (i < total) {
+    locate(i, k_next, t_next);
+    r_next = recs[t_next];
+    item_next = rec_item[t_next];
+  }
+  while (i < total) {
+    const PointRec<A> r = r_next;
+    const long item = item_next;
+    const int k = k_next;
+    i += CPI;
+    if (i < total) {
+      locate(i, k_next, t_next);
+      r_next = recs[t_next];
+      item_next = rec_item[t_next];
     }
+    A go[VEC];
+    Elem<VT>::unpack(*reinterpret_cast<const u32x4*>(grad_out + item * C + cv * VEC), go);
+    const A wt = ((k & 4) ? r.ld : A(1) - r.ld) * ((k & 2) ? r.lh : A(1) - r.lh) *
+                 ((k & 1) ? r.lw : A(1) - r.lw) * r.a;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += wt * go[e];
   }
 
 #pragma unroll

@@ -82,16 +82,21 @@ class FocusedAttn(nn.Module):
         else:
             self.pos_bias = None
 
-    def _roi_attention(self, q, k, v, roi):
-        """Per-organ attention over the organ's own keys.  roi = (index (O,L)
-        long, pad (O,L) bool True=padding); queries are organ-major."""
+    def _roi_attention(self, q, v, k_pos, roi):
+        """Per-organ attention over the organ's own keys; keys = v + k_pos.
+        roi = (index (O,L) long, pad (O,L) bool True=padding); queries are
+        organ-major."""
         index, pad = roi
         b, n_q, c = q.shape
         n_org, n_keys = index.shape
         qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
+        # gather the organ's tokens BEFORE the projections: one scatter in the backward
+        # (d_src = Wk^T dk + Wv^T dv) instead of one per projection
         flat = index.reshape(-1)
-        kk = _GatherTokens.apply(self.k_proj(k), flat).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
-        vv = _GatherTokens.apply(self.v_proj(v), flat).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        v_tok = _GatherTokens.apply(v, flat)                               # (B, O*L, C)
+        k_tok = v_tok if k_pos is None else v_tok + k_pos.index_select(1, flat)
+        kk = self.k_proj(k_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        vv = self.v_proj(v_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
         attn = qq @ kk.transpose(-2, -1)                                  # (B, O, h, qpo, L)
         if self.pos_bias is not None:
@@ -101,11 +106,14 @@ class FocusedAttn(nn.Module):
         x = self.attn_drop(attn) @ vv                                     # (B, O, h, qpo, hd)
         return x.permute(0, 1, 3, 2, 4).reshape(b, n_q, c)
 
-    def forward(self, q, k, v, mask=None, need_weights=False, roi=None):
+    def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None):
         """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf; roi: the
-        same mask as per-organ key lists.  Returns (out, weights or None)."""
-        if roi is not None and not need_weights:
-            return self.proj_drop(self.proj(self._roi_attention(q, k, v, roi))), None
+        same mask as per-organ key lists.  k_pos: if given, the keys are
+        ``v + k_pos`` and ``k`` may be None.  Returns (out, weights or None)."""
+        if roi is not None and not need_weights and (k_pos is not None or k is v):
+            return self.proj_drop(self.proj(self._roi_attention(q, v, k_pos, roi))), None
+        if k is None:
+            k = v + k_pos
         b, n_kv, c = k.shape
         n_q = q.shape[1]
         h, hd = self.num_heads, c // self.num_heads
@@ -211,9 +219,9 @@ class FocusedDecoderLayer(nn.Module):
         tgt = self.norm2(tgt + self.dropout2(sa))
 
         q = tgt if query_pos is None else tgt + query_pos
-        k = src if src_pos is None else src + src_pos
         roi = (self.roi_index, self.roi_pad) if self._use_roi else None
-        ca, weights = self.cross_attn(q, k, src, mask=self.attn_bias, need_weights=need_weights, roi=roi)
+        ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self.attn_bias,
+                                      need_weights=need_weights, roi=roi, k_pos=src_pos)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
         ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))

@@ -14,6 +14,8 @@ reference dispatches float/double only, .cu:64), kernel launch errors raise
 ``im2col_step`` only takes part in the reference's divisibility check -- the
 batch is processed in one launch.
 """
+import ctypes
+
 import torch
 
 from . import _native
@@ -24,6 +26,26 @@ _DT = {torch.float32: _native.F32, torch.float64: _native.F64,
 # bit set forwarded to the C ABI (see include/transoar_msda3d.h); module-level so
 # tests can force the generic kernels.
 flags = 0
+
+
+# host copies of spatial_shapes tensors, keyed on the tensor's storage: the reference passes
+# the level shapes as a device tensor only; one .tolist() (a sync) per distinct tensor buys the
+# brick schedule of the kernels.  locality_hint = False skips it (schedule only, same results).
+locality_hint = True
+_host_shapes = {}
+
+
+def _shapes_on_host(spatial_shapes):
+    if not locality_hint:
+        return None, None
+    key = (spatial_shapes.data_ptr(), spatial_shapes.device, spatial_shapes._version, tuple(spatial_shapes.shape))
+    hit = _host_shapes.get(key)
+    if hit is None:
+        if len(_host_shapes) > 64:
+            _host_shapes.clear()
+        arr = (ctypes.c_int64 * spatial_shapes.numel())(*[int(v) for v in spatial_shapes.flatten().tolist()])
+        hit = _host_shapes[key] = arr
+    return hit, ctypes.addressof(hit)
 
 
 def _require(cond, msg):
@@ -84,12 +106,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                                  attn_weight, im2col_step)
     sampling_loc, attn_weight = _coerce_loc(value, sampling_loc, attn_weight)
     out = torch.empty((N, Lq, M * C), dtype=value.dtype, device=value.device)
+    _keep, host_ptr = _shapes_on_host(spatial_shapes)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _native.lib.transoar_msda3d_forward(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-            N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype], flags, stream)
+            N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype], host_ptr, flags, stream)
     _native.check(rc, "transoar_msda3d_forward")
     return out
 
@@ -113,12 +136,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     dims = (N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype])
     ws_bytes = _native.lib.transoar_msda3d_backward_workspace_bytes(*dims, flags)
     workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=value.device)
+    _keep, host_ptr = _shapes_on_host(spatial_shapes)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = _native.lib.transoar_msda3d_backward(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
             grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-            workspace.data_ptr(), ws_bytes, *dims, flags, stream)
+            workspace.data_ptr(), ws_bytes, *dims, host_ptr, flags, stream)
     _native.check(rc, "transoar_msda3d_backward")
     return [grad_value, grad_loc.to(loc_in_dtype), grad_attn.to(attn_in_dtype)]
