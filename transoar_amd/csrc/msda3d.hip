@@ -107,6 +107,8 @@ static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
   const long n_points = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
   const long n_bins = static_cast<long>(d.N) * d.M * 8 * d.S;
   if (value_bytes >= 0xfffffff0L || n_points >= (1L << 31) - 1 || n_bins >= (1L << 31) - 1) return -1;
+  // row index and row pitch go through the 24-bit multiplier
+  if (static_cast<long>(d.N) * d.S >= (1L << 24) || static_cast<long>(d.M) * d.C * elt >= (1L << 24)) return -1;
   return lpv_log2(d.C, elt);
 }
 

@@ -71,6 +71,26 @@ __device__ __forceinline__ PointGeo<A> point_geometry(const LT* __restrict__ loc
   return g;
 }
 
+// Lane-constant description of the trilinear corner a lane fetches with its
+// i-th load of a point: corner bits (dd,dh,dw), the axis weight as c + s*frac
+// ((1,-1) for the low corner, (0,+1) for the high one; s is also the sign of
+// d(weight)/d(frac)), row-offset masks and the validity bits it needs.
+template <typename A> struct CornerConst {
+  A cd, sd, ch, sh, cw, sw;
+  int mask_d, mask_h, dw, need;
+};
+template <typename A>
+__device__ __forceinline__ CornerConst<A> corner_const(int k) {
+  const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
+  CornerConst<A> c;
+  c.cd = dd ? A(0) : A(1); c.sd = dd ? A(1) : A(-1);
+  c.ch = dh ? A(0) : A(1); c.sh = dh ? A(1) : A(-1);
+  c.cw = dw ? A(0) : A(1); c.sw = dw ? A(1) : A(-1);
+  c.mask_d = -dd; c.mask_h = -dh; c.dw = dw;
+  c.need = (1 << dd) | (4 << dh) | (16 << dw);
+  return c;
+}
+
 __device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // ---------------------------------------------------------------------------
@@ -105,6 +125,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_vec(
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<VT*>(value), 0, static_cast<int>(value_bytes), 0x00020000);
 
+  CornerConst<A> corner[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) corner[i] = corner_const<A>(i * CPI + cg);
   const LT* loc_i = loc + item * LP * 3;
   const LT* attn_i = attn + item * LP;
 
@@ -126,13 +149,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_fwd_vec(
         const int W = bcast(g.W, jj), HW = bcast(g.HW, jj);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const int k = i * CPI + cg;  // corner: bit2 = d, bit1 = h, bit0 = w
-          const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
-          const bool valid = ((ok >> dd) & (ok >> (2 + dh)) & (ok >> (4 + dw)) & 1) != 0;
-          const int r = base + dd * HW + dh * W + dw;
-          const unsigned voff = valid ? head_off + static_cast<unsigned>(r) * row_bytes : 0xfffffff0u;
+          const CornerConst<A>& cc = corner[i];
+          const bool valid = (ok & cc.need) == cc.need;
+          const int r = base + (HW & cc.mask_d) + (W & cc.mask_h) + cc.dw;
+          const unsigned voff = valid ? head_off + __umul24(static_cast<unsigned>(r), row_bytes) : 0xfffffff0u;
           raw[t][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-          wt[t][i] = (dd ? ld : A(1) - ld) * (dh ? lh : A(1) - lh) * (dw ? lw : A(1) - lw) * a;
+          // (1-x) or x per axis as c + s*x with lane constants
+          wt[t][i] = (cc.cd + cc.sd * ld) * (cc.ch + cc.sh * lh) * ((cc.cw + cc.sw * lw) * a);
         }
       }
 #pragma unroll
@@ -194,6 +217,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<VT*>(value), 0, static_cast<int>(value_bytes), 0x00020000);
 
+  CornerConst<A> corner[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) corner[i] = corner_const<A>(i * CPI + cg);
   const LT* loc_i = loc + item * LP * 3;
   const LT* attn_i = attn + item * LP;
 
@@ -218,11 +244,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
           const int W = bcast(g.W, jj), HW = bcast(g.HW, jj);
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const int k = i * CPI + cg;
-            const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
-            const bool valid = ((ok >> dd) & (ok >> (2 + dh)) & (ok >> (4 + dw)) & 1) != 0;
-            const int r = base + dd * HW + dh * W + dw;
-            const unsigned voff = valid ? head_off + static_cast<unsigned>(r) * row_bytes : 0xfffffff0u;
+            const CornerConst<A>& cc = corner[i];
+            const bool valid = (ok & cc.need) == cc.need;
+            const int r = base + (HW & cc.mask_d) + (W & cc.mask_h) + cc.dw;
+            const unsigned voff = valid ? head_off + __umul24(static_cast<unsigned>(r), row_bytes) : 0xfffffff0u;
             raw[t][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
           }
         }
@@ -232,19 +257,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
           const A ld = bcast(g.ld, jj), lh = bcast(g.lh, jj), lw = bcast(g.lw, jj);
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const int k = i * CPI + cg;
-            const int dd = (k >> 2) & 1, dh = (k >> 1) & 1, dw = k & 1;
+            const CornerConst<A>& cc = corner[i];
             A v[VEC];
             Elem<VT>::unpack(raw[t][i], v);
             A dot = A(0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dot += go[e] * v[e];
-            const A wd = dd ? ld : A(1) - ld, wh = dh ? lh : A(1) - lh, ww = dw ? lw : A(1) - lw;
+            const A wd = cc.cd + cc.sd * ld, wh = cc.ch + cc.sh * lh, ww = cc.cw + cc.sw * lw;
             // d(corner weight)/d(axis) = +-(product of the other two axis weights)
             part[4 * jj + 0] += (wd * wh * ww) * dot;
-            part[4 * jj + 1] += (dw ? dot : -dot) * (wd * wh);
-            part[4 * jj + 2] += (dh ? dot : -dot) * (wd * ww);
-            part[4 * jj + 3] += (dd ? dot : -dot) * (wh * ww);
+            part[4 * jj + 1] += (cc.sw * dot) * (wd * wh);
+            part[4 * jj + 2] += (cc.sh * dot) * (wd * ww);
+            part[4 * jj + 3] += (cc.sd * dot) * (wh * ww);
           }
         }
       }
