@@ -109,6 +109,9 @@ static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
   if (value_bytes >= 0xfffffff0L || n_points >= (1L << 31) - 1 || n_bins >= (1L << 31) - 1) return -1;
   // row index and row pitch go through the 24-bit multiplier
   if (static_cast<long>(d.N) * d.S >= (1L << 24) || static_cast<long>(d.M) * d.C * elt >= (1L << 24)) return -1;
+  if (n_points * 32 >= 0xfffffff0L) return -1;   // record array addressed with 32-bit byte offsets
+  if (static_cast<long>(d.N) * d.Lq * d.M >= (1L << 24) ||
+      static_cast<long>(d.N) * d.Lq * d.M * d.C * elt >= 0x7ffffff0L) return -1;
   return lpv_log2(d.C, elt);
 }
 
@@ -263,13 +266,15 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   }
 
   // 3. grad_value rows
-  const BrickOrder r_order = make_order(host_shapes, d, d.S);
+  BrickOrder r_order = make_order(host_shapes, d, d.S);
+  if (r_order.enabled && (flags & TRANSOAR_MSDA3D_PULL_HEAD_MAJOR)) r_order.enabled = 2;
   const long n_rows = order_units(r_order, d, d.S);
   const long r_blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
   const dim3 rgrid(((r_blocks + 7) / 8) * 8);
 #define TRANSOAR_PULL(LG)                                                                        \
   hipLaunchKernelGGL((msda3d_bwd_value_pull<VT, A, LG>), rgrid, block, 0, st, go, shapes, lsi, count, \
-                     recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks, r_order)
+                     recs, rec_item, static_cast<VT*>(grad_value), d.S, d.M, d.C, d.L, n_rows, r_blocks, r_order, \
+                     static_cast<unsigned>(w.n_points * 4 * sizeof(A)))
   {
     ProfScope prof(TRANSOAR_PROF_PULL, st);
     if (lg == 3) TRANSOAR_PULL(3);

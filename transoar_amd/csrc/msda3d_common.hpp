@@ -216,11 +216,23 @@ __device__ __forceinline__ int brick_slot_to_row(const BrickOrder& o, int x) {
 // R = rows per batch element (S or Lq).
 __device__ __forceinline__ long ordered_unit(const BrickOrder& o, long u, int R, int M) {
   if (!o.enabled) return u;
-  const int m = static_cast<int>(u % M);
-  const long t = u / M;
   const int total = o.pad_start[o.L];
-  const int x = static_cast<int>(t % total);
-  const long b = t / total;
+  int m, x;
+  long b;
+  if (o.enabled == 2) {        // brick-major: all 128 slots of a brick for one head, then the next head
+    const int slot = static_cast<int>(u & 127);
+    const long t = u >> 7;
+    m = static_cast<int>(t % M);
+    const long t2 = t / M;
+    const int bricks = total >> 7;
+    x = static_cast<int>(t2 % bricks) * 128 + slot;
+    b = t2 / bricks;
+  } else {                     // head-minor: the heads of one voxel are consecutive waves
+    m = static_cast<int>(u % M);
+    const long t = u / M;
+    x = static_cast<int>(t % total);
+    b = t / total;
+  }
   const int r = brick_slot_to_row(o, x);
   return r < 0 ? -1 : (b * R + r) * M + m;
 }

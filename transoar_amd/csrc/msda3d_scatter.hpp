@@ -26,6 +26,7 @@ namespace transoar {
 
 template <typename A> struct alignas(16) PointRec { A ld, lh, lw, a; };
 
+constexpr int kPullUnroll = 4;
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;                       // per thread
 constexpr int kScanTile = kScanThreads * kScanItems;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_value_pull(
     const int64_t* __restrict__ lsi, const int* __restrict__ offset,
     const PointRec<A>* __restrict__ recs, const int* __restrict__ rec_item,
     VT* __restrict__ grad_value, int S, int M, int C, int L, long n_units, long n_blocks,
-    BrickOrder order) {
+    BrickOrder order, unsigned rec_bytes) {
   constexpr int VEC = Elem<VT>::VEC;
   constexpr int LPV = 1 << LOG2_LPV;
   constexpr int CPI = 64 / LPV;   // records handled per load instruction
@@ -244,29 +245,58 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_value_pull(
       if (i >= pre[j]) { k = j; t = i - pre[j] + beg[j]; }
   };
 
-  int i = cg, k_next = 0, t_next = 0, item_next = 0;
-  PointRec<A> r_next{A(0), A(0), A(0), A(0)};
-  if (i < total) {
-    locate(i, k_next, t_next);
-    r_next = recs[t_next];
-    item_next = rec_item[t_next];
-  }
-  while (i < total) {
-    const PointRec<A> r = r_next;
-    const long item = item_next;
-    const int k = k_next;
-    i += CPI;
-    if (i < total) {
-      locate(i, k_next, t_next);
-      r_next = recs[t_next];
-      item_next = rec_item[t_next];
-    }
-    A go[VEC];
-    Elem<VT>::unpack(*reinterpret_cast<const u32x4*>(grad_out + item * C + cv * VEC), go);
-    const A wt = ((k & 4) ? r.ld : A(1) - r.ld) * ((k & 2) ? r.lh : A(1) - r.lh) *
-                 ((k & 1) ? r.lw : A(1) - r.lw) * r.a;
+  // kPullUnroll records per lane group are in flight together (records, then their grad_out
+  // rows): the kernel is bound by bytes in flight per wave (Little's law), not by bandwidth.
+  constexpr int U = kPullUnroll;
+  const unsigned c_bytes = static_cast<unsigned>(C) * sizeof(VT);
+  const unsigned lane_off = static_cast<unsigned>(cv * VEC * sizeof(VT));
+  const __amdgpu_buffer_rsrc_t gr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<VT*>(grad_out), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<PointRec<A>*>(recs), 0, static_cast<int>(rec_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(rec_item), 0, static_cast<int>(rec_bytes / (sizeof(PointRec<A>) / 4)), 0x00020000);
+  for (int i0 = cg; i0 < total; i0 += CPI * U) {
+    // branch-free: a lane group that has run out of records reads out of range (zeros) and
+    // contributes weight 0, so all 2*U record loads issue back to back
+    PointRec<A> rc[U];
+    int item[U], kk[U];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] += wt * go[e];
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * CPI;
+      const bool live = i < total;
+      int t;
+      locate(live ? i : 0, kk[u], t);
+      const unsigned tu = live ? static_cast<unsigned>(t) : 0x0fffffffu;
+      if constexpr (sizeof(A) == 4) {
+        const u32x4 raw_rec = __builtin_amdgcn_raw_buffer_load_b128(rr, tu * 16u, 0, 0);
+        rc[u].ld = __uint_as_float(raw_rec[0]);
+        rc[u].lh = __uint_as_float(raw_rec[1]);
+        rc[u].lw = __uint_as_float(raw_rec[2]);
+        rc[u].a = __uint_as_float(raw_rec[3]);
+      } else {
+        rc[u] = live ? recs[t] : PointRec<A>{A(0), A(0), A(0), A(0)};
+      }
+      const int it = __builtin_amdgcn_raw_buffer_load_b32(ir, tu * 4u, 0, 0);
+      item[u] = live ? it : -1;
+    }
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // a finished group reads nothing: out-of-range offset -> zeros from the buffer unit
+      const unsigned off = item[u] >= 0 ? __umul24(static_cast<unsigned>(item[u]), c_bytes) + lane_off : 0xfffffff0u;
+      raw[u] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      A go[VEC];
+      Elem<VT>::unpack(raw[u], go);
+      const int k = kk[u];
+      const A wt = ((k & 4) ? rc[u].ld : A(1) - rc[u].ld) * ((k & 2) ? rc[u].lh : A(1) - rc[u].lh) *
+                   ((k & 1) ? rc[u].lw : A(1) - rc[u].lw) * rc[u].a;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += wt * go[e];
+    }
   }
 
 #pragma unroll
