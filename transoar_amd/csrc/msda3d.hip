@@ -223,10 +223,27 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 
   const dim3 grid(((n_blocks + 7) / 8) * 8);
   const unsigned vbytes = static_cast<unsigned>(value_elems * sizeof(VT));
-  // 1. grad_loc / grad_attn
+  const BwdWorkspace w = bwd_workspace(d, sizeof(A));
+  char* ws = static_cast<char*>(workspace);
+  int* count = reinterpret_cast<int*>(ws + w.count);
+  int* tile_sums = reinterpret_cast<int*>(ws + w.tile_sums);
+  int* rank = reinterpret_cast<int*>(ws + w.rank);
+  int* rec_item = reinterpret_cast<int*>(ws + w.rec_item);
+  auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
+  TRANSOAR_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * w.n_scan, st));
+  // cells per (batch, head) slab: needs the level shapes on the host; without them the binning
+  // runs as its own kernel (msda3d_cell_count) after the gather
+  long cells_per_slab = 0;
+  if (host_shapes)
+    for (int l = 0; l < d.L; ++l)
+      cells_per_slab += (host_shapes[3 * l] + 1) * (host_shapes[3 * l + 1] + 1) * (host_shapes[3 * l + 2] + 1);
+  const bool fold_count = host_shapes != nullptr && cells_per_slab * d.N * d.M <= w.n_bins;
+
+  // 1. grad_loc / grad_attn (+ the binning pass of the point sort when folded)
 #define TRANSOAR_BWDQ(LG)                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
-                     at, go, gl, ga, d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
+                     at, go, gl, ga, fold_count ? count : nullptr, rank, static_cast<int>(cells_per_slab), \
+                     d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
   {
     ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
     if (lg == 3) TRANSOAR_BWDQ(3);
@@ -236,16 +253,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 #undef TRANSOAR_BWDQ
 
   // 2. sort the sampling points by cell
-  const BwdWorkspace w = bwd_workspace(d, sizeof(A));
-  char* ws = static_cast<char*>(workspace);
-  int* count = reinterpret_cast<int*>(ws + w.count);
-  int* tile_sums = reinterpret_cast<int*>(ws + w.tile_sums);
-  int* rank = reinterpret_cast<int*>(ws + w.rank);
-  int* rec_item = reinterpret_cast<int*>(ws + w.rec_item);
-  auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
-  TRANSOAR_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * w.n_scan, st));
   const dim3 pgrid(static_cast<unsigned>((w.n_points + 255) / 256));
-  {
+  if (!fold_count) {
     ProfScope prof(TRANSOAR_PROF_CELL_COUNT, st);
     hipLaunchKernelGGL((msda3d_cell_count<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
                        rank, d.M, d.L, d.Lq, d.P, w.n_points);

@@ -31,9 +31,10 @@ template <typename A> struct PointGeo {
   int base_row;      // row of corner (d0,h0,w0) inside value[b] (may be < 0)
   int ok;            // bits 0-1: d lo/hi in range, 2-3: h, 4-5: w ; 0 if skipped
   int W, HW;         // row strides of the point's level
+  int cell;          // padded-grid cell of (d0,h0,w0) within a (batch, head) slab, -1 if skipped
 };
 
-template <typename LT, typename A>
+template <typename LT, typename A, bool WITH_CELL = false>
 __device__ __forceinline__ PointGeo<A> point_geometry(const LT* __restrict__ loc_i,
                                                       const LT* __restrict__ attn_i,
                                                       const int64_t* __restrict__ shapes,
@@ -44,6 +45,7 @@ __device__ __forceinline__ PointGeo<A> point_geometry(const LT* __restrict__ loc
   g.base_row = 0;
   g.ok = 0;
   g.W = g.HW = 0;
+  g.cell = -1;
   if (active) {
     int l = 0;
     for (int t = 1; t < L; ++t) l += (j >= t * P) ? 1 : 0;
@@ -66,6 +68,14 @@ __device__ __forceinline__ PointGeo<A> point_geometry(const LT* __restrict__ loc
       g.base_row = start + (d0 * H + h0) * W + w0;
       g.ok = (d0 >= 0 ? 1 : 0) | (d0 + 1 < D ? 2 : 0) | (h0 >= 0 ? 4 : 0) | (h0 + 1 < H ? 8 : 0) |
              (w0 >= 0 ? 16 : 0) | (w0 + 1 < W ? 32 : 0);
+      if (WITH_CELL) {
+        // same bin as msda3d_scatter.hpp:point_bin -- padded grid (D+1)(H+1)(W+1) per level
+        int cell_start = 0;
+        for (int t = 0; t < l; ++t)
+          cell_start += (static_cast<int>(shapes[3 * t]) + 1) * (static_cast<int>(shapes[3 * t + 1]) + 1) *
+                        (static_cast<int>(shapes[3 * t + 2]) + 1);
+        g.cell = cell_start + ((d0 + 1) * (H + 1) + (h0 + 1)) * (W + 1) + (w0 + 1);
+      }
     }
   }
   return g;
@@ -191,7 +201,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc,
     const LT* __restrict__ attn, const VT* __restrict__ grad_out,
-    LT* __restrict__ grad_loc, LT* __restrict__ grad_attn, int S, int M, int C,
+    LT* __restrict__ grad_loc, LT* __restrict__ grad_attn, int* __restrict__ bin_count,
+    int* __restrict__ bin_rank, int cells_per_slab, int S, int M, int C,
     int L, int Lq, int P, unsigned value_bytes, long n_units, long n_blocks, BrickOrder order) {
   using A = typename Elem<VT>::acc;
   constexpr int VEC = Elem<VT>::VEC;
@@ -228,7 +239,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void msda3d_bwd_query_vec(
 
   for (int j0 = 0; j0 < LP; j0 += kChunk) {
     const int nj = min(kChunk, LP - j0);
-    const PointGeo<A> g = point_geometry<LT, A>(loc_i, attn_i, shapes, lsi, j0 + lane, lane < nj, L, P);
+    const PointGeo<A> g = point_geometry<LT, A, true>(loc_i, attn_i, shapes, lsi, j0 + lane, lane < nj, L, P);
+    // first pass of the grad_value counting sort, folded in here: this lane already holds the
+    // point's cell; the returned atomic's latency hides behind the gathers below
+    if (bin_count != nullptr && lane < nj) {
+      const int bin = static_cast<int>(b * M + m) * cells_per_slab + g.cell;
+      bin_rank[item * LP + j0 + lane] = g.cell < 0 ? -1 : atomicAdd(bin_count + bin, 1);
+    }
     A part[4 * kChunk];
 #pragma unroll
     for (int i = 0; i < 4 * kChunk; ++i) part[i] = A(0);
