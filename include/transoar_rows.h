@@ -1,0 +1,26 @@
+/*
+ * transoar_rows.h -- C ABI of the row gather / inverse gather used by the
+ * Focused Decoder's per-organ key lists (host code: transoar_amd/focused_decoder.py;
+ * reference semantics: the -inf mask of necks/focused_decoder.py:138-159,238-247).
+ * Device pointers, 16-byte aligned rows, asynchronous on `hip_stream`; returns 0,
+ * a hipError_t, -1 (NULL) or -2 (bad size).
+ */
+#ifndef TRANSOAR_ROWS_H
+#define TRANSOAR_ROWS_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[b][k][:] = src[b][index[k]][:]   src (B,S,row) out (B,K,row), index int32 (K) */
+int transoar_rows_gather(const void* src, const int* index, void* out, int B, long S, long K,
+                         int row_bytes, void* hip_stream);
+
+/* out[b][s][:] = sum_{i in [inv_ptr[s], inv_ptr[s+1])} g[b][inv_idx[i]][:]   (fp32 or bf16 rows,
+ * fp32 accumulation); inv_ptr int32 (S+1), inv_idx int32: the CSR inverse of `index`. */
+int transoar_rows_pull_sum(const void* g, const int* inv_ptr, const int* inv_idx, void* out, int B,
+                           long S, long K, int row_bytes, int is_bf16, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

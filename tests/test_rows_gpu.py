@@ -1,0 +1,27 @@
+"""GPU: row gather / inverse-gather kernels vs torch indexing."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rows_gather_and_pull_sum(dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import rows
+    g = torch.Generator().manual_seed(0)
+    B, S, C, K = 2, 500, 48, 1300
+    x = torch.randn(B, S, C, generator=g).to(dtype).cuda()
+    index = torch.randint(0, S, (K,), generator=g)
+    out = rows.gather(x, index.int().cuda())
+    assert torch.equal(out, x[:, index.cuda()])
+    # CSR inverse
+    order = torch.argsort(index, stable=True)
+    counts = torch.bincount(index, minlength=S)
+    ptr = torch.cat((counts.new_zeros(1), counts.cumsum(0))).int().cuda()
+    gy = torch.randn(B, K, C, generator=g).to(dtype).cuda()
+    got = rows.pull_sum(gy, ptr, order.int().cuda(), S)
+    ref = torch.zeros(B, S, C, device="cuda").index_add_(1, index.cuda(), gy.float())
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -7
+    assert float((got.float() - ref).abs().max()) <= tol * float(ref.abs().max())

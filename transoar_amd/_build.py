@@ -19,6 +19,7 @@ LIBS = {
     "libtransoar_msda3d.so": ["msda3d.hip"],
     "libtransoar_conv3d.so": ["conv3d.hip"],
     "libtransoar_instnorm.so": ["instnorm.hip"],
+    "libtransoar_rows.so": ["rows.hip"],
 }
 
 

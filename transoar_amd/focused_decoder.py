@@ -28,6 +28,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import rows
+
 _LEVEL_SHAPES = {
     20: {"P0": (160, 160, 256), "P1": (80, 80, 128), "P2": (40, 40, 64), "P3": (20, 20, 32),
          "P4": (10, 10, 16), "P5": (5, 5, 8)},
@@ -44,22 +46,28 @@ def _activation(name):
 
 
 class _GatherTokens(torch.autograd.Function):
-    """x (B, S, C), index (K,) -> x[:, index].  The backward is an fp32
-    index_add_ (hardware float atomics) instead of autograd's sort-based
-    index_put_ for advanced indexing, which costs ~100x more here."""
+    """x (B, S, C), index (K,) -> x[:, index].  On the GPU both directions are
+    the hand-written row kernels (include/transoar_rows.h): forward a row
+    gather, backward a pull over the static CSR inverse of ``index`` (no
+    atomics).  Elsewhere: index_select / fp32 index_add_."""
 
     @staticmethod
-    def forward(ctx, x, index):
-        ctx.save_for_backward(index)
+    def forward(ctx, x, index, inverse):
         ctx.n_tokens = x.shape[1]
-        return x.index_select(1, index)
+        ctx.save_for_backward(index, *(inverse or ()))
+        if rows.usable(x):
+            return rows.gather(x, index)
+        return x.index_select(1, index.long())
 
     @staticmethod
     def backward(ctx, g):
-        (index,) = ctx.saved_tensors
+        index, *inverse = ctx.saved_tensors
+        g = g.contiguous()
+        if inverse and rows.usable(g):
+            return rows.pull_sum(g, inverse[0], inverse[1], ctx.n_tokens), None, None
         gx = torch.zeros(g.shape[0], ctx.n_tokens, g.shape[2], dtype=torch.float32, device=g.device)
-        gx.index_add_(1, index, g.float())
-        return gx.to(g.dtype), None
+        gx.index_add_(1, index.long(), g.float())
+        return gx.to(g.dtype), None, None
 
 
 class FocusedAttn(nn.Module):
@@ -86,22 +94,27 @@ class FocusedAttn(nn.Module):
         """Per-organ attention over the organ's own keys; keys = v + k_pos.
         roi = (index (O,L) long, pad (O,L) bool True=padding); queries are
         organ-major."""
-        index, pad = roi
+        index, pad, inverse = roi[0], roi[1], roi[2:]
         b, n_q, c = q.shape
         n_org, n_keys = index.shape
         qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
         # gather the organ's tokens BEFORE the projections: one scatter in the backward
         # (d_src = Wk^T dk + Wv^T dv) instead of one per projection
         flat = index.reshape(-1)
-        v_tok = _GatherTokens.apply(v, flat)                               # (B, O*L, C)
-        k_tok = v_tok if k_pos is None else v_tok + k_pos.index_select(1, flat)
+        v_tok = _GatherTokens.apply(v.contiguous(), flat, inverse)         # (B, O*L, C)
+        if k_pos is None:
+            k_tok = v_tok
+        elif rows.usable(k_pos) and k_pos.is_contiguous():
+            k_tok = v_tok + rows.gather(k_pos, flat)
+        else:
+            k_tok = v_tok + k_pos.index_select(1, flat.long())
         kk = self.k_proj(k_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         vv = self.v_proj(v_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
         attn = qq @ kk.transpose(-2, -1)                                  # (B, O, h, qpo, L)
         if self.pos_bias is not None:
             attn = attn + self.pos_bias.view(n_org, qpo, -1).gather(
-                2, index[:, None, :].expand(-1, qpo, -1))[None, :, None]
+                2, index.long()[:, None, :].expand(-1, qpo, -1))[None, :, None]
         attn = attn.masked_fill(pad[None, :, None, None, :], float("-inf")).softmax(dim=-1)
         x = self.attn_drop(attn) @ vv                                     # (B, O, h, qpo, hd)
         return x.permute(0, 1, 3, 2, 4).reshape(b, n_q, c)
@@ -157,8 +170,16 @@ class FocusedDecoderLayer(nn.Module):
         roi = self._roi_lists()
         self._use_roi = roi is not None
         if roi is not None:
-            self.register_buffer("roi_index", roi[0], persistent=False)
+            self.register_buffer("roi_index", roi[0].int(), persistent=False)
             self.register_buffer("roi_pad", roi[1], persistent=False)
+            # CSR inverse of the flattened key lists (which list slots hold token s), for the backward
+            flat = roi[0].reshape(-1)
+            live = (~roi[1]).reshape(-1).nonzero().flatten()
+            order = live[torch.argsort(flat[live], stable=True)]
+            counts = torch.bincount(flat[live], minlength=self.attn_mask.shape[1])
+            self.register_buffer("roi_inv_ptr", torch.cat((counts.new_zeros(1), counts.cumsum(0))).int(),
+                                 persistent=False)
+            self.register_buffer("roi_inv_idx", order.int(), persistent=False)
         self.cross_attn = FocusedAttn(d_model, n_heads, self.attn_mask, proj_drop=0.1)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -219,7 +240,7 @@ class FocusedDecoderLayer(nn.Module):
         tgt = self.norm2(tgt + self.dropout2(sa))
 
         q = tgt if query_pos is None else tgt + query_pos
-        roi = (self.roi_index, self.roi_pad) if self._use_roi else None
+        roi = (self.roi_index, self.roi_pad, self.roi_inv_ptr, self.roi_inv_idx) if self._use_roi else None
         ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self.attn_bias,
                                       need_weights=need_weights, roi=roi, k_pos=src_pos)
         tgt = self.norm1(tgt + self.dropout1(ca))

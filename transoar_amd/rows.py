@@ -1,0 +1,48 @@
+"""ctypes shim of the row gather / inverse-gather kernels (include/transoar_rows.h)."""
+import ctypes
+import os
+
+import torch
+
+from . import _native  # noqa: F401
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtransoar_rows.so")
+if not os.path.exists(_LIB_PATH):
+    raise _native.NativeLibraryError("%s is not built (python transoar_amd/_build.py)" % _LIB_PATH)
+lib = ctypes.CDLL(_LIB_PATH)
+_i, _p, _l = ctypes.c_int, ctypes.c_void_p, ctypes.c_long
+lib.transoar_rows_gather.restype = _i
+lib.transoar_rows_gather.argtypes = [_p, _p, _p, _i, _l, _l, _i, _p]
+lib.transoar_rows_pull_sum.restype = _i
+lib.transoar_rows_pull_sum.argtypes = [_p, _p, _p, _p, _i, _l, _l, _i, _i, _p]
+
+
+def usable(x):
+    return (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16)
+            and (x.shape[2] * x.element_size()) % 16 == 0)
+
+
+def gather(x, index):
+    """x (B,S,C) contiguous, index int32 (K,) -> (B,K,C)"""
+    b, s, c = x.shape
+    k = index.numel()
+    out = torch.empty((b, k, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_rows_gather(x.data_ptr(), index.data_ptr(), out.data_ptr(), b, s, k,
+                                      c * x.element_size(), torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise RuntimeError("transoar_rows_gather failed with code %d" % rc)
+    return out
+
+
+def pull_sum(g, inv_ptr, inv_idx, n_tokens):
+    """g (B,K,C) contiguous -> (B,S,C): sum of the rows listed per token"""
+    b, k, c = g.shape
+    out = torch.empty((b, n_tokens, c), dtype=g.dtype, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib.transoar_rows_pull_sum(g.data_ptr(), inv_ptr.data_ptr(), inv_idx.data_ptr(), out.data_ptr(), b,
+                                        n_tokens, k, c * g.element_size(), 1 if g.dtype == torch.bfloat16 else 0,
+                                        torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise RuntimeError("transoar_rows_pull_sum failed with code %d" % rc)
+    return out
