@@ -273,6 +273,7 @@ class FocusedDecoder(nn.Module):
         self.d_model, self.nhead = d_model, nhead
         layer = FocusedDecoderLayer(d_model, dim_feedforward, dropout, activation, nhead, config, bbox_props)
         self.decoder = FocusedDecoderModel(layer, num_decoder_layers, return_intermediate_dec)
+        self._pos_tokens = {}
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -281,8 +282,15 @@ class FocusedDecoder(nn.Module):
         """src/pos (N, C, D, H, W); query_embed (Q, 2C) = [query_pos | tgt]
         -> (layers, N, Q, C)"""
         assert query_embed is not None
-        src = src.flatten(2).transpose(1, 2)
-        pos = pos.flatten(2).transpose(1, 2)
+        src = src.flatten(2).transpose(1, 2)            # a free view when src is channels-last
+        if pos.requires_grad:
+            pos = pos.flatten(2).transpose(1, 2)
+        else:                                           # sine encoding: input independent, cache its token form
+            key = (tuple(pos.shape), pos.device)
+            hit = self._pos_tokens.get(key)
+            if hit is None:
+                hit = self._pos_tokens[key] = pos.flatten(2).transpose(1, 2).contiguous()
+            pos = hit
         n, _, c = src.shape
         query_pos, tgt = query_embed.split(c, dim=1)
         return self.decoder(tgt[None].expand(n, -1, -1), src, pos, query_pos[None].expand(n, -1, -1))

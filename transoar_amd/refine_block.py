@@ -18,6 +18,42 @@ from torch import nn
 from .ms_deform_attn import MSDeformAttn
 
 
+class _MapToTokens(torch.autograd.Function):
+    """(N, C, D, H, W) bf16 NCDHW map -> (N, D*H*W, C) contiguous tokens through the
+    layout kernel (and back in the backward).  The stock path
+    ``f.flatten(2).transpose(1, 2)`` hands nn.Linear a transposed view, which
+    costs hipBLASLt a 4x slower GEMM variant on the 117 000-token pyramid."""
+
+    @staticmethod
+    def forward(ctx, fmap):
+        from .conv3d import to_ndhwc
+        ctx.shape = fmap.shape
+        n, c = fmap.shape[:2]
+        return to_ndhwc(fmap).permute(0, 2, 3, 4, 1).reshape(n, -1, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .conv3d import to_ncdhw
+        n, c, d, h, w = ctx.shape
+        g = g.contiguous().view(n, d, h, w, c).permute(0, 4, 1, 2, 3)      # channels_last_3d view
+        return to_ncdhw(g) if g.dtype == torch.bfloat16 else g.contiguous()
+
+
+def map_to_tokens(fmap):
+    if fmap.is_cuda and fmap.dtype == torch.bfloat16 and fmap.shape[1] % 8 == 0:
+        return _MapToTokens.apply(fmap)
+    return fmap.flatten(2).transpose(1, 2)
+
+
+def tokens_to_map(tokens, shape):
+    """(N, V, C) -> (N, C, D, H, W); a channels_last_3d VIEW when the tokens are
+    contiguous (no copy), which later flattens back to tokens for free."""
+    n, _, c = tokens.shape
+    if tokens.is_contiguous():
+        return tokens.view(n, *shape, c).permute(0, 4, 1, 2, 3)
+    return tokens.transpose(1, 2).reshape(n, c, *shape)
+
+
 def _activation(name):
     try:
         return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[name]
@@ -116,10 +152,20 @@ class DecoderDefAttnBlock(nn.Module):
         maps with the same shapes."""
         shapes = tuple(tuple(f.shape[2:]) for f in fmaps)
         spatial, starts, sizes, ref = self._level_geometry(shapes, fmaps[0].device)
-        tokens = torch.cat([f.flatten(2) for f in fmaps], dim=2).transpose(1, 2)          # (N, S, C)
-        pos = torch.cat([p.flatten(2) + self.level_embed[lvl].view(1, -1, 1).to(p.dtype)
-                         for lvl, p in enumerate(pos_embeds)], dim=2).transpose(1, 2)
+        # token-major (N, S, C), contiguous: what the projections and the kernels read
+        tokens = torch.cat([map_to_tokens(f) for f in fmaps], dim=1)
+        pos = torch.cat([self._pos_tokens(p, lvl) + self.level_embed[lvl].view(1, 1, -1).to(p.dtype)
+                         for lvl, p in enumerate(pos_embeds)], dim=1)
         memory = self.refine_def_attn(tokens, spatial, starts, pos, ref)
-        n, c = fmaps[0].shape[:2]
-        return [m.transpose(1, 2).reshape(n, c, *shape)
-                for m, shape in zip(memory.split(sizes, dim=1), shapes)]
+        return [tokens_to_map(m.contiguous(), shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
+
+    def _pos_tokens(self, pos_map, lvl):
+        """(N, C, D, H, W) positional map -> (N, V, C) tokens; the sine encoding
+        is input independent, so its token form is cached per level and shape."""
+        key = ("pos", lvl, tuple(pos_map.shape), pos_map.device, pos_map.requires_grad)
+        if pos_map.requires_grad:                       # learned encoding: no caching
+            return pos_map.flatten(2).transpose(1, 2)
+        hit = self._geometry.get(key)
+        if hit is None:
+            hit = self._geometry[key] = pos_map.flatten(2).transpose(1, 2).contiguous()
+        return hit
