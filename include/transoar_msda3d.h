@@ -68,6 +68,7 @@ enum {
 
 /* flags (bit set) */
 #define TRANSOAR_MSDA3D_FORCE_GENERIC 1u  /* skip the vectorised kernels   */
+#define TRANSOAR_MSDA3D_NO_BRICK 4u        /* forward: per-item kernel even where the LDS-tiled one applies */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*

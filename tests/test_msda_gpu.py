@@ -288,6 +288,26 @@ def test_brick_schedule_is_only_a_schedule(MSDA):
         res[hint] = (MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64),
                      *MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 64))
     MSDA.locality_hint = True
-    assert torch.equal(res[True][0], res[False][0])          # forward: same arithmetic per item
+    assert torch.equal(res[True][0], res[False][0])          # forward (fp32): same kernel, same arithmetic per item
     for a, b in zip(res[True][1:], res[False][1:]):
         assert relerr(a, b) <= 1e-5
+
+
+@pytest.mark.parametrize("vdt", [torch.bfloat16, torch.float16])
+def test_lds_brick_forward_matches_per_item_kernel(MSDA, vdt):
+    """16-bit storage + host shapes + C=64, P=4 takes the LDS-tiled brick kernel; flag 4 forces
+    the per-item kernel.  Local (model-like) and non-local (uniform -> global fallback inside
+    the brick kernel) sampling, odd level extents."""
+    levels = [(9, 6, 11), (5, 3, 6), (2, 2, 3)]
+    value, shapes, lsi, loc, attn = _inputs.model_like_inputs(5, 2, levels, device="cuda")
+    v = value.to(vdt)
+    f = lambda t: t.float().cpu().numpy()
+    for locs in (loc, torch.rand_like(loc) * 1.4 - 0.2):
+        MSDA.flags = 0
+        a = MSDA.ms_deform_attn_forward(v, shapes, lsi, locs, attn, 64)
+        MSDA.flags = 4
+        b = MSDA.ms_deform_attn_forward(v, shapes, lsi, locs, attn, 64)
+        MSDA.flags = 0
+        ref = c_oracle.forward(f(v), shapes.cpu().numpy(), lsi.cpu().numpy(), f(locs), f(attn))
+        assert relerr(a, torch.from_numpy(ref)) <= TOL[vdt]
+        assert relerr(a, b) <= TOL[vdt]

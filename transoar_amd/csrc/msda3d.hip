@@ -12,6 +12,7 @@
 
 #include "../../include/transoar_msda3d.h"
 #include "msda3d_common.hpp"
+#include "msda3d_brick.hpp"
 #include "msda3d_gather.hpp"
 #include "msda3d_generic.hpp"
 #include "msda3d_scatter.hpp"
@@ -150,6 +151,17 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
   auto lo = static_cast<const LT*>(loc);
   auto at = static_cast<const LT*>(attn);
   auto o = static_cast<VT*>(out);
+  // LDS-tiled brick kernel: queries are the pyramid's voxels (Lq == S), host knows the shapes,
+  // 64 channels per head, 4 points per level (the refine block's configuration)
+  // (16-bit storage only: an fp32 box of the finest level does not fit the 48 KiB tile)
+  if (lg >= 0 && order.enabled && d.C == 64 && d.P == 4 && sizeof(VT) == 2 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
+    ProfScope prof(TRANSOAR_PROF_FWD, st);
+    const long n_wg = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M;
+    const dim3 bgrid(((n_wg + 7) / 8) * 8);
+    hipLaunchKernelGGL((msda3d_fwd_brick<VT, LT, 4, 64>), bgrid, dim3(kBrickThreads), kTileBytes, st, v, lo, at, o,
+                       d.S, d.M, d.L, n_wg, order);
+    return static_cast<int>(hipGetLastError());
+  }
   if (lg < 0) {
     ProfScope prof(TRANSOAR_PROF_FWD_GENERIC, st);
     hipLaunchKernelGGL((msda3d_fwd_generic<VT, LT>), dim3((n_items + kWavesPerBlock - 1) / kWavesPerBlock),
