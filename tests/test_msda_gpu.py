@@ -311,3 +311,10 @@ def test_lds_brick_forward_matches_per_item_kernel(MSDA, vdt):
         ref = c_oracle.forward(f(v), shapes.cpu().numpy(), lsi.cpu().numpy(), f(locs), f(attn))
         assert relerr(a, torch.from_numpy(ref)) <= TOL[vdt]
         assert relerr(a, b) <= TOL[vdt]
+        # backward: brick grad_loc / grad_attn (+ folded binning -> grad_value) vs the oracle
+        go = torch.randn(a.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)).to(vdt)
+        gv, gl, ga = MSDA.ms_deform_attn_backward(v, shapes, lsi, locs, attn, go, 64)
+        rgv, rgl, rga = c_oracle.backward(f(v), shapes.cpu().numpy(), lsi.cpu().numpy(), f(locs), f(attn), f(go))
+        assert relerr(gv, torch.from_numpy(rgv)) <= TOL[vdt]
+        assert relerr(gl, torch.from_numpy(rgl)) <= 1e-4
+        assert relerr(ga, torch.from_numpy(rga)) <= 1e-4

@@ -177,4 +177,187 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_fwd_brick(
   }
 }
 
+// ---------------------------------------------------------------------------
+// grad_sampling_loc / grad_attn_weight, same tiling.  A thread holds the
+// grad_out half-row of its query; per corner it dots it with the LDS row, the
+// two halves of a query meet through one lane exchange per point, and half 0
+// writes the point's 4 gradients.  Also does the binning pass of the
+// grad_value point sort (one int atomic per point, see msda3d_scatter.hpp).
+// ---------------------------------------------------------------------------
+template <typename VT, int NV>
+__device__ __forceinline__ typename Elem<VT>::acc dot_row(const u32x4* __restrict__ src,
+                                                          const typename Elem<VT>::acc (&go)[NV * Elem<VT>::VEC]) {
+  constexpr int VEC = Elem<VT>::VEC;
+  typename Elem<VT>::acc d = 0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    typename Elem<VT>::acc v[VEC];
+    Elem<VT>::unpack(src[i], v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d += go[i * VEC + e] * v[e];
+  }
+  return d;
+}
+
+template <typename VT, typename LT, int P, int C>
+__global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
+    const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
+    const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
+    int* __restrict__ bin_count, int* __restrict__ bin_rank, int cells_per_slab, int S, int M, int L,
+    long n_wg, BrickOrder order) {
+  using A = typename Elem<VT>::acc;
+  constexpr int VEC = Elem<VT>::VEC;
+  constexpr int CPT = C / 2;
+  constexpr int NV = CPT / VEC;
+  constexpr int ROW_BYTES = C * sizeof(VT);
+  constexpr int PITCH = ROW_BYTES + 16;
+  constexpr int ROW_VECS = ROW_BYTES / 16;
+  constexpr int TILE_ROWS = kTileBytes / PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+  __shared__ int box[6];
+
+  const long wg = xcd_contiguous_block(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int tid = threadIdx.x;
+  const int m = static_cast<int>(wg % M);
+  const long t1 = wg / M;
+  const int bricks = order.pad_start[order.L] >> 7;
+  const int brick = static_cast<int>(t1 % bricks);
+  const long b = t1 / bricks;
+  const int q_slot = tid >> 1, half = tid & 1;
+  const int s = brick_slot_to_row(order, brick * kBrickSlots + q_slot);
+  const bool live = s >= 0;
+  const long item = live ? (b * S + s) * M + m : 0;
+  const int LP = L * P;
+  const long row_stride = static_cast<long>(M) * C;
+  const VT* vhead = value + (b * S * M + m) * C + half * CPT;
+
+  A go[CPT];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    A v[VEC];
+    u32x4 raw = {0u, 0u, 0u, 0u};
+    if (live) raw = reinterpret_cast<const u32x4*>(grad_out + item * C + half * CPT)[i];
+    Elem<VT>::unpack(raw, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) go[i * VEC + e] = v[e];
+  }
+
+  int cell_start = 0;
+  for (int l = 0; l < L; ++l) {
+    const int D = order.D[l], H = order.H[l], W = order.W[l], start = order.start[l];
+    A ld[P], lh[P], lw[P], aw[P];
+    int d0[P], h0[P], w0[P], rank[P];
+    bool ok[P];
+    int lo_d = 1 << 30, lo_h = 1 << 30, lo_w = 1 << 30, hi_d = -1, hi_h = -1, hi_w = -1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      ok[p] = false;
+      rank[p] = -1;
+      ld[p] = lh[p] = lw[p] = aw[p] = A(0);
+      d0[p] = h0[p] = w0[p] = 0;
+      if (live) {
+        const long j = item * LP + l * P + p;
+        const A w_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j)), W);
+        const A h_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 1)), H);
+        const A d_im = pixel_coord(static_cast<A>(Elem<LT>::ld(loc + 3 * j + 2)), D);
+        if (d_im > A(-1) && h_im > A(-1) && w_im > A(-1) && d_im < D && h_im < H && w_im < W) {
+          const A fd = floor(d_im), fh = floor(h_im), fw = floor(w_im);
+          d0[p] = static_cast<int>(fd); h0[p] = static_cast<int>(fh); w0[p] = static_cast<int>(fw);
+          ld[p] = d_im - fd; lh[p] = h_im - fh; lw[p] = w_im - fw;
+          aw[p] = static_cast<A>(Elem<LT>::ld(attn + j));
+          ok[p] = true;
+          lo_d = min(lo_d, max(d0[p], 0)); hi_d = max(hi_d, min(d0[p] + 1, D - 1));
+          lo_h = min(lo_h, max(h0[p], 0)); hi_h = max(hi_h, min(h0[p] + 1, H - 1));
+          lo_w = min(lo_w, max(w0[p], 0)); hi_w = max(hi_w, min(w0[p] + 1, W - 1));
+          if (half == 0 && bin_count != nullptr) {
+            // the returned rank is only stored after the sampling loop: its latency hides there
+            const int cell = cell_start + ((d0[p] + 1) * (H + 1) + (h0[p] + 1)) * (W + 1) + (w0[p] + 1);
+            rank[p] = atomicAdd(bin_count + static_cast<int>(b * M + m) * cells_per_slab + cell, 1);
+          }
+        }
+      }
+    }
+    cell_start += (D + 1) * (H + 1) * (W + 1);
+    if (tid < 3) box[tid] = 1 << 30;
+    else if (tid < 6) box[tid] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      lo_d = min(lo_d, __shfl_xor(lo_d, off, 64)); hi_d = max(hi_d, __shfl_xor(hi_d, off, 64));
+      lo_h = min(lo_h, __shfl_xor(lo_h, off, 64)); hi_h = max(hi_h, __shfl_xor(hi_h, off, 64));
+      lo_w = min(lo_w, __shfl_xor(lo_w, off, 64)); hi_w = max(hi_w, __shfl_xor(hi_w, off, 64));
+    }
+    if ((tid & 63) == 0) {
+      atomicMin(&box[0], lo_d); atomicMin(&box[1], lo_h); atomicMin(&box[2], lo_w);
+      atomicMax(&box[3], hi_d); atomicMax(&box[4], hi_h); atomicMax(&box[5], hi_w);
+    }
+    __syncthreads();
+    const int bd = box[0], bh = box[1], bw = box[2];
+    const int TD = box[3] - bd + 1, TH = box[4] - bh + 1, TW = box[5] - bw + 1;
+    const bool any = box[3] >= 0;
+    const int rows = TD * TH * TW;
+    const bool staged = any && rows <= TILE_ROWS;
+    if (staged) {
+      const int THW = TH * TW;
+      for (int i = tid; i < rows * ROW_VECS; i += kBrickThreads) {
+        const int r = i / ROW_VECS, v = i - r * ROW_VECS;
+        const int rd = r / THW, rr = r - rd * THW;
+        const int rh = rr / TW, rw = rr - rh * TW;
+        const long grow = start + (static_cast<long>(bd + rd) * H + (bh + rh)) * W + (bw + rw);
+        *reinterpret_cast<u32x4*>(tile + r * PITCH + v * 16) =
+            *reinterpret_cast<const u32x4*>(value + ((b * S + grow) * M + m) * C + v * VEC);
+      }
+      __syncthreads();
+    }
+    A res_loc[3 * P], res_attn[P];     // this level's outputs of the query: 48 + 16 contiguous bytes
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      A pa = A(0), px = A(0), py = A(0), pz = A(0);
+      if (ok[p]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+          const int d = d0[p] + dd, h = h0[p] + dh, w = w0[p] + dw;
+          if (static_cast<unsigned>(d) < static_cast<unsigned>(D) && static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
+              static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
+            A dot;
+            if (staged) {
+              const int r = ((d - bd) * TH + (h - bh)) * TW + (w - bw);
+              dot = dot_row<VT, NV>(reinterpret_cast<const u32x4*>(tile + r * PITCH + half * (CPT * sizeof(VT))), go);
+            } else {
+              const long grow = start + (static_cast<long>(d) * H + h) * W + w;
+              dot = dot_row<VT, NV>(reinterpret_cast<const u32x4*>(vhead + grow * row_stride), go);
+            }
+            const A wd = dd ? ld[p] : A(1) - ld[p], wh = dh ? lh[p] : A(1) - lh[p], ww = dw ? lw[p] : A(1) - lw[p];
+            pa += (wd * wh * ww) * dot;
+            px += (dw ? dot : -dot) * (wd * wh);
+            py += (dh ? dot : -dot) * (wd * ww);
+            pz += (dd ? dot : -dot) * (wh * ww);
+          }
+        }
+      }
+      // the two channel halves of the query sit in neighbouring lanes
+      pa += __shfl_xor(pa, 1, 64); px += __shfl_xor(px, 1, 64);
+      py += __shfl_xor(py, 1, 64); pz += __shfl_xor(pz, 1, 64);
+      res_attn[p] = pa;
+      res_loc[3 * p] = px * aw[p] * static_cast<A>(W);
+      res_loc[3 * p + 1] = py * aw[p] * static_cast<A>(H);
+      res_loc[3 * p + 2] = pz * aw[p] * static_cast<A>(D);
+    }
+    if (live && half == 0) {
+      const long j0 = item * LP + l * P;
+      if (bin_count != nullptr) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) bin_rank[j0 + p] = rank[p];
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) Elem<LT>::st(grad_attn + j0 + p, res_attn[p]);
+#pragma unroll
+      for (int i = 0; i < 3 * P; ++i) Elem<LT>::st(grad_loc + 3 * j0 + i, res_loc[i]);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace transoar
