@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager step (default: fwd+loss+bwd captured in a HIP graph)")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
@@ -140,7 +141,7 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
-    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp)
+    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.rand(args.batch, 1, *cfg["volume_shape"], device=dev, generator=g)
@@ -153,16 +154,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_mode = "eager"
+    step(x, targets)                           # one eager step first (lazy init, MIOpen find-db lookups)
+    if not args.no_graph:
+        try:
+            step.capture(x, targets)
+            step_mode = "hip-graph(fwd+loss+bwd) + eager all-reduce + fused AdamW"
+        except Exception as e:                 # keep going eagerly, say so in the output
+            import traceback
+            traceback.print_exc()
+            step_mode = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120],)
+            step._graph = None
+            step.reducer.overlap = True
     for _ in range(args.warmup):
         step(x, targets)
     barrier()
-    _native.profile_enable(True)
-    _native.profile_read()
+    if step._graph is None:                    # eager: time the kernels over the timed steps themselves
+        _native.profile_enable(True)
+        _native.profile_read()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         total, _ = step(x, targets)
+        host_s += time.perf_counter() - h0          # time the host needs to ENQUEUE a step (no sync)
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the
+    # launch stream.  A replayed graph re-records nothing, so in graph mode they come from eager steps of
+    # the same model state run right after the timed replays (kernel durations do not depend on how the
+    # launch was issued); in eager mode they are taken over the timed steps themselves.
+    prof_steps = args.steps
+    if step._graph is not None:
+        graph, step._graph = step._graph, None
+        step.reducer.overlap = True
+        prof_steps = 3
+        _native.profile_enable(True)
+        _native.profile_read()
+        for _ in range(prof_steps):
+            step(x, targets)
+        torch.cuda.synchronize()
+        step._graph = graph
     _native.profile_enable(False)
     prof = _native.profile_read()
     if world > 1:
@@ -184,7 +216,7 @@ def main():
                 continue
             avg = ms / n
             b = msda_algorithmic_bytes(kind, **dims)
-            kernels[kind] = {"launches_per_step": n / args.steps, "avg_ms": round(avg, 4),
+            kernels[kind] = {"launches_per_step": n / prof_steps, "avg_ms": round(avg, 4),
                              "algorithmic_MB": round(b / 1e6, 1),
                              "achieved_GBps": round(b / avg / 1e6, 1) if b else None}
         roofline = None
@@ -196,7 +228,9 @@ def main():
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kd["achieved_GBps"] / HBM_PEAK_GBPS, 4),
                         "traffic": pmc_traffic(dom, dims), "traffic_unit": "MB per launch (PMC, profiles/r01_msda_pmc.json)",
                         "avg_launch_ms": kd["avg_ms"], "algorithmic_MB": kd["algorithmic_MB"],
-                        "timing": "hipEvent pairs on the launch stream inside the timed region"}
+                        "timing": "hipEvent pairs on the launch stream, " + (
+                            "timed steps" if step_mode == "eager" or step_mode.startswith("eager") else
+                            "3 eager steps right after the timed graph replays")}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -218,8 +252,9 @@ def main():
                                                                                      "on (use_decoder_attn, use_cuda)"),
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "volume": list(cfg["volume_shape"]),
                        "parallelism": "dp%d" % world, "weights": "random init", "optimizer": "AdamW fused",
+                       "step_mode": step_mode,
                        "params": sum(p.numel() for p in model.parameters())},
-            "loss": round(loss_value, 5),
+            "loss": round(loss_value, 5), "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
             "roofline": roofline, "msda_kernels": kernels, "cpu_baseline": cpu,
         }))
     if world > 1:

@@ -9,17 +9,23 @@ def box_cxcyczwhd_to_xyzxyz(b):
     return torch.cat((c - 0.5 * s, c + 0.5 * s), dim=-1)
 
 
+def _prod3(t):
+    # explicit product of the three extents: Tensor.prod's backward checks for zeros on the
+    # host (a device->host sync, and illegal inside a captured HIP graph)
+    return t[..., 0] * t[..., 1] * t[..., 2]
+
+
 def _volume(b):
-    return (b[..., 3:] - b[..., :3]).prod(-1)
+    return _prod3(b[..., 3:] - b[..., :3])
 
 
 def elementwise_giou_3d(a, b):
     """GIoU of box pairs, broadcasting over leading dims; boxes x1y1z1x2y2z2.
     Equals the reference's pairwise matrix entry for (a_i, b_j)."""
-    inter = (torch.min(a[..., 3:], b[..., 3:]) - torch.max(a[..., :3], b[..., :3])).clamp(min=0).prod(-1)
+    inter = _prod3((torch.min(a[..., 3:], b[..., 3:]) - torch.max(a[..., :3], b[..., :3])).clamp(min=0))
     union = _volume(a) + _volume(b) - inter
     iou = inter / union
-    hull = (torch.max(a[..., 3:], b[..., 3:]) - torch.min(a[..., :3], b[..., :3])).clamp(min=0).prod(-1)
+    hull = _prod3((torch.max(a[..., 3:], b[..., 3:]) - torch.min(a[..., :3], b[..., :3])).clamp(min=0))
     return iou - (hull - union) / hull
 
 

@@ -42,14 +42,18 @@ class _Bucket:
 
 
 class GradientAllReducer:
-    def __init__(self, module, process_group=None, bucket_bytes=48 << 20):
+    def __init__(self, module, process_group=None, bucket_bytes=48 << 20, always_flat=False):
+        """always_flat: build the flat gradient buckets even for one rank (the captured-graph
+        training step needs gradients at fixed addresses that can be zeroed with a few memsets)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1
+        self.flat = self.active or always_flat
+        self.overlap = True          # launch a bucket's all-reduce from the autograd hook
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets, self._bucket_of, self._hooks = [], {}, []
         self._fired, self._first_step = set(), True
-        if not self.active:
+        if not self.flat:
             return
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -60,8 +64,9 @@ class GradientAllReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._add_bucket(cur)
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.active:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _add_bucket(self, params):
         b = _Bucket(list(params), params[0].device, params[0].dtype)
@@ -79,7 +84,7 @@ class GradientAllReducer:
 
     def begin(self):
         """Call before forward/backward: zero the gradient buckets."""
-        if not self.active:
+        if not self.flat:
             for p in self.params:
                 p.grad = None
             return
@@ -97,13 +102,16 @@ class GradientAllReducer:
         if self._first_step:
             self._fired.add(p)
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and self.overlap:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward, before the optimizer: wait for every bucket."""
         if not self.active:
             return
+        if not self.overlap:         # captured-graph step: the exchange runs after the replay
+            for b in self.buckets:
+                b.handle = None
         for b in self.buckets:
             if b.handle is None:     # first step only: a parameter without gradient held it back
                 b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
