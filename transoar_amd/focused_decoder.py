@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import rows
+from .token_linear import token_linear
 
 _LEVEL_SHAPES = {
     20: {"P0": (160, 160, 256), "P1": (80, 80, 128), "P2": (40, 40, 64), "P3": (20, 20, 32),
@@ -108,8 +109,8 @@ class FocusedAttn(nn.Module):
             k_tok = v_tok + rows.gather(k_pos, flat)
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())
-        kk = self.k_proj(k_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
-        vv = self.v_proj(v_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        kk = token_linear(k_tok, self.k_proj.weight, self.k_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+        vv = token_linear(v_tok, self.v_proj.weight, self.v_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
         attn = qq @ kk.transpose(-2, -1)                                  # (B, O, h, qpo, L)
         if self.pos_bias is not None:

@@ -25,6 +25,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import msda as MSDA
+from .token_linear import token_linear
 
 _debug_core = None
 
@@ -126,13 +127,18 @@ class MSDeformAttn(nn.Module):
                              % reference_points.shape[-1])
         m, lv, pt = self.n_heads, self.n_levels, self.n_points
 
-        value = self.value_proj(input_flatten)
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(n, s, m, self.d_model // m)
 
-        offsets = self.sampling_offsets(query).view(n, lq, m, lv, pt, 3)
-        weights = F.softmax(self.attention_weights(query).view(n, lq, m, lv * pt), dim=-1)
+        # both projections read `query`: one GEMM over the stacked weights (the
+        # parameters stay separate, as in the reference's state dict)
+        n_off = self.sampling_offsets.out_features
+        proj = token_linear(query, torch.cat((self.sampling_offsets.weight, self.attention_weights.weight)),
+                            torch.cat((self.sampling_offsets.bias, self.attention_weights.bias)))
+        offsets = proj[..., :n_off].unflatten(-1, (m, lv, pt, 3))
+        weights = F.softmax(proj[..., n_off:].unflatten(-1, (m, lv * pt)), dim=-1)
         weights = weights.view(n, lq, m, lv, pt)
         # offsets are in voxels of their level: divide by (W,H,D)
         whd = input_spatial_shapes.flip(-1).to(offsets.dtype)
@@ -148,4 +154,4 @@ class MSDeformAttn(nn.Module):
                     "debug core lives in oracle/torch_ref.py; a test harness may inject it with "
                     "transoar_amd.ms_deform_attn.register_debug_core().")
             sampled = _debug_core(value, input_spatial_shapes, locations, weights)
-        return self.output_proj(sampled)
+        return token_linear(sampled, self.output_proj.weight, self.output_proj.bias)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .ms_deform_attn import MSDeformAttn
+from .token_linear import token_linear
 
 
 class _MapToTokens(torch.autograd.Function):
@@ -80,7 +81,8 @@ class DefAttnLayer(nn.Module):
         query = src if pos is None else src + pos
         attn = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(attn))
-        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ffn))
 
 

@@ -1,0 +1,75 @@
+"""nn.Linear over the flattened feature pyramid (10^5 tokens per volume).
+
+Forward and input gradient are ordinary hipBLASLt GEMMs.  The weight gradient
+dW = dY^T X contracts over the TOKEN axis (K = 234 000 at batch 2) into a tile
+of at most 1024 x 384: hipBLASLt covers that with a few dozen workgroups on a
+256-CU part (0.5-0.9 ms, 40-230 TFLOP/s measured).  Here the token axis is cut
+into chunks that run as one batched GEMM with fp32 partial outputs, summed
+afterwards -- 3-5x faster (tools/probe_wgrad.py), and the partial sums stay in
+fp32 exactly like the single GEMM's accumulator.
+
+Same arithmetic contract as autocast's nn.Linear: bf16 operands, fp32
+accumulation, bf16 output; parameters and their gradients stay fp32.
+"""
+import torch
+import torch.nn.functional as F
+
+MIN_TOKENS = 32768          # below this the stock path is as fast
+
+
+def _chunks(tokens, n_out, n_in):
+    tiles = -(-n_out // 64) * -(-n_in // 128)
+    want = max(8, min(80, 1440 // max(tiles, 1)))
+    size = max(1024, tokens // want)
+    return tokens // size, size
+
+
+def weight_grad(gy, x):
+    """(T, N)^T @ (T, K) -> (N, K) fp32, token axis in batched chunks."""
+    t, n = gy.shape
+    k = x.shape[1]
+    b, size = _chunks(t, n, k)
+    main = b * size
+    out = torch.bmm(gy[:main].view(b, size, n).transpose(1, 2), x[:main].view(b, size, k),
+                    out_dtype=torch.float32).sum(0)
+    if main < t:
+        out = out + torch.mm(gy[main:].t(), x[main:], out_dtype=torch.float32)
+    return out
+
+
+class _TokenLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb = x.to(torch.bfloat16)
+        wb = weight.to(torch.bfloat16)
+        ctx.save_for_backward(xb, wb)
+        ctx.in_dtype, ctx.has_bias = x.dtype, bias is not None
+        with torch.autocast("cuda", enabled=False):
+            return F.linear(xb, wb, None if bias is None else bias.to(torch.bfloat16))
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        gy = gy.to(torch.bfloat16)
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        gx = gw = gb = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                gx = torch.mm(gy2, wb).view(xb.shape).to(ctx.in_dtype)
+            if ctx.needs_input_grad[1]:
+                gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = gy2.sum(0, dtype=torch.float32)
+        return gx, gw, gb
+
+
+def token_linear(x, weight, bias=None):
+    """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
+    bf16 autocast on the GPU with enough tokens, the stock one otherwise."""
+    tokens = x.numel() // x.shape[-1]
+    if (x.is_cuda and tokens >= MIN_TOKENS and weight.dtype == torch.float32 and x.is_contiguous()
+            and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+        return _TokenLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
