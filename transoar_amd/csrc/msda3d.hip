@@ -13,6 +13,7 @@
 #include "../../include/transoar_msda3d.h"
 #include "msda3d_common.hpp"
 #include "msda3d_brick.hpp"
+#include "msda3d_tile.hpp"
 #include "msda3d_gather.hpp"
 #include "msda3d_generic.hpp"
 #include "msda3d_scatter.hpp"
@@ -117,7 +118,7 @@ static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
 }
 
 struct BwdWorkspace {
-  size_t count, tile_sums, rank, rec_item, recs, total;
+  size_t count, tile_sums, rank, rec_item, recs, coarse, total;
   long n_bins, n_points, n_scan, n_tiles;
 };
 
@@ -132,7 +133,8 @@ static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
   w.tile_sums = off; off += align16(sizeof(int) * w.n_tiles);
   w.rank = off;      off += align16(sizeof(int) * w.n_points);
   w.rec_item = off;  off += align16(sizeof(int) * w.n_points);
-  w.recs = off;      off += align16(4 * acc_size * w.n_points);
+  w.recs = off;      off += align16(8 * acc_size * w.n_points);   // PointW8 (tile path) or PointRec
+  w.coarse = off;    off += align16(sizeof(float) * static_cast<size_t>(d.N) * d.S * d.M * d.C);   // fp32 rows of the coarse levels
   w.total = off;
   return w;
 }
@@ -286,6 +288,53 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   hipLaunchKernelGGL(msda3d_scan_add, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0, st,
                      count, tile_sums, static_cast<int>(w.n_scan));
   }
+  BrickOrder r_order = make_order(host_shapes, d, d.S);
+  if constexpr (sizeof(A) == 4) {
+    // brick-owner schedule: fp32 LDS tile per 4x4x8 brick, 8-weight point records
+    if (r_order.enabled && fold_count && d.C == kTileC && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
+      auto recs8 = reinterpret_cast<PointW8<float>*>(ws + w.recs);
+      {
+        ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
+        hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                           rank, recs8, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
+      }
+      ProfScope prof(TRANSOAR_PROF_PULL, st);
+      // levels where a cell holds >= 128 points on average go to the chunked walk
+      CoarseLevels cl{d.L, static_cast<int>(cells_per_slab), d.S, 0, 0};
+      for (int l = d.L - 1; l >= 0; --l) {
+        const long vox = host_shapes[3 * l] * host_shapes[3 * l + 1] * host_shapes[3 * l + 2];
+        if (static_cast<long>(d.Lq) * d.P < 128 * vox) break;
+        cl.first = l;
+        cl.cell_start -= static_cast<int>((host_shapes[3 * l] + 1) * (host_shapes[3 * l + 1] + 1) * (host_shapes[3 * l + 2] + 1));
+        cl.row_start = r_order.start[l];
+      }
+      cl.rows = d.S - cl.row_start;
+      const int coarse_levels = d.L - cl.first;
+      cl.chunks_per_slab = static_cast<int>((static_cast<long>(d.Lq) * d.P * coarse_levels + kCellChunk - 1) / kCellChunk) + 1;
+      const int fine_bricks = r_order.pad_start[cl.first] >> 7;
+      float* scratch = reinterpret_cast<float*>(ws + w.coarse);
+      const long scratch_elems = static_cast<long>(d.N) * cl.rows * d.M * kTileC;
+      if (coarse_levels > 0) {
+        TRANSOAR_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * scratch_elems, st));
+        const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
+        hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, st,
+                           go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl,
+                           r_order);
+      }
+      if (fine_bricks > 0) {
+        const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
+        hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
+                           count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
+                           d.S, d.M, fine_bricks, n_wg, r_order);
+      }
+      if (coarse_levels > 0) {
+        const long n4 = scratch_elems / 4;
+        hipLaunchKernelGGL((msda3d_coarse_rows_store<VT>), dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, st,
+                           scratch, static_cast<VT*>(grad_value), d.S, d.M, cl, n4);
+      }
+      return static_cast<int>(hipGetLastError());
+    }
+  }
   {
     ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
     hipLaunchKernelGGL((msda3d_cell_fill<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
@@ -293,7 +342,6 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   }
 
   // 3. grad_value rows
-  BrickOrder r_order = make_order(host_shapes, d, d.S);
   if (r_order.enabled && (flags & TRANSOAR_MSDA3D_PULL_HEAD_MAJOR)) r_order.enabled = 2;
   const long n_rows = order_units(r_order, d, d.S);
   const long r_blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
