@@ -318,3 +318,35 @@ def test_lds_brick_forward_matches_per_item_kernel(MSDA, vdt):
         assert relerr(gv, torch.from_numpy(rgv)) <= TOL[vdt]
         assert relerr(gl, torch.from_numpy(rgl)) <= 1e-4
         assert relerr(ga, torch.from_numpy(rga)) <= 1e-4
+
+
+@pytest.mark.parametrize("levels,Lq", [
+    ([(2, 2, 3), (1, 1, 2)], 2000),      # every level "coarse": the chunked cell walk alone
+    ([(9, 6, 11)], 50),                   # one fine level: the LDS tile walk alone
+    ([(7, 9, 17), (4, 5, 9), (2, 3, 5)], 1500),   # both, queries != pyramid rows, odd extents
+])
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+def test_grad_value_tile_and_cell_walks_vs_c_oracle(MSDA, levels, Lq, vdt):
+    """grad_value with C=64 and host shapes: fine levels are accumulated per 4x4x8 brick in an
+    LDS tile, levels with >=128 points per voxel by chunks of sorted points with row atomics.
+    Locations reach outside [0,1] so border cells (floor = -1, size-1) are populated."""
+    shapes = torch.as_tensor(levels, dtype=torch.long)
+    N, M, C, L, P = 2, 3, 64, len(levels), 4
+    value, loc, attn = rand_inputs(11, N, M, C, Lq, L, P, shapes, torch.float32, -0.15, 1.15)
+    lsi = level_starts(shapes)
+    go = torch.randn(N, Lq, M * C, generator=torch.Generator().manual_seed(2)).to(vdt)
+    v = value.to(vdt)
+    f = lambda t: t.float().numpy()
+    rgv, rgl, rga = c_oracle.backward(f(v), shapes.numpy(), lsi.numpy(), f(loc), f(attn), f(go))
+    MSDA.locality_hint = True
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v.cuda(), shapes.cuda(), lsi.cuda(), loc.cuda(), attn.cuda(),
+                                              go.cuda(), 64)
+    assert gv.dtype == vdt
+    assert relerr(gv, torch.from_numpy(rgv)) <= TOL[vdt]
+    assert relerr(gl, torch.from_numpy(rgl)) <= 1e-4
+    assert relerr(ga, torch.from_numpy(rga)) <= 1e-4
+    # and the voxel-stationary pull (no host shapes) agrees
+    MSDA.locality_hint = False
+    gv2 = MSDA.ms_deform_attn_backward(v.cuda(), shapes.cuda(), lsi.cuda(), loc.cuda(), attn.cuda(), go.cuda(), 64)[0]
+    MSDA.locality_hint = True
+    assert relerr(gv, gv2) <= TOL[vdt]

@@ -112,6 +112,12 @@ class FocusedAttn(nn.Module):
         kk = token_linear(k_tok, self.k_proj.weight, self.k_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         vv = token_linear(v_tok, self.v_proj.weight, self.v_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
+        if self.pos_bias is None and q.is_cuda and not (self.training and self.attn_drop.p > 0):
+            # fused attention over the strided head views: no (B,O,h,L,hd) copies, no (qpo x L) score tensor
+            keep = (~pad)[None, :, None, None, :].expand(b, n_org, 1, 1, n_keys).reshape(b * n_org, 1, 1, n_keys)
+            x = F.scaled_dot_product_attention(qq.reshape(b * n_org, h, qpo, hd), kk.reshape(b * n_org, h, n_keys, hd),
+                                               vv.reshape(b * n_org, h, n_keys, hd), attn_mask=keep, scale=1.0)
+            return x.view(b, n_org, h, qpo, hd).permute(0, 1, 3, 2, 4).reshape(b, n_q, c)
         attn = qq @ kk.transpose(-2, -1)                                  # (B, O, h, qpo, L)
         if self.pos_bias is not None:
             attn = attn + self.pos_bias.view(n_org, qpo, -1).gather(
