@@ -350,3 +350,21 @@ def test_grad_value_tile_and_cell_walks_vs_c_oracle(MSDA, levels, Lq, vdt):
     gv2 = MSDA.ms_deform_attn_backward(v.cuda(), shapes.cuda(), lsi.cuda(), loc.cuda(), attn.cuda(), go.cuda(), 64)[0]
     MSDA.locality_hint = True
     assert relerr(gv, gv2) <= TOL[vdt]
+
+
+def test_host_shape_copy_follows_the_tensor_not_its_address(MSDA):
+    """The host copy of spatial_shapes (brick schedule) must never outlive its tensor: a new
+    shapes tensor allocated at a recycled address has different level extents."""
+    MSDA.locality_hint = True
+    for levels in ([(4, 4, 8), (2, 2, 4)], [(3, 5, 7), (2, 3, 4)], [(6, 2, 9), (1, 1, 2)], [(4, 4, 8), (2, 2, 4)]):
+        shapes = torch.as_tensor(levels, dtype=torch.long)
+        S = int(shapes.prod(1).sum())
+        value, loc, attn = rand_inputs(3, 1, 2, 64, S, 2, 4, shapes, torch.float32)
+        lsi = level_starts(shapes)
+        v16 = value.to(torch.bfloat16)
+        f = lambda t: t.float().numpy()
+        ref = c_oracle.forward(f(v16), shapes.numpy(), lsi.numpy(), f(loc), f(attn))
+        dev_shapes = shapes.cuda()              # freed at the end of the iteration; the next one may reuse the address
+        out = MSDA.ms_deform_attn_forward(v16.cuda(), dev_shapes, lsi.cuda(), loc.cuda(), attn.cuda(), 64)
+        assert relerr(out, torch.from_numpy(ref)) <= TOL[torch.bfloat16]
+        del dev_shapes

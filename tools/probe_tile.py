@@ -9,7 +9,7 @@ print("shapes", shapes.tolist(), "loc", tuple(loc.shape))
 v = value.to(torch.bfloat16); go = torch.randn(v.shape[0], loc.shape[1], v.shape[2] * v.shape[3], device="cuda").to(torch.bfloat16)
 names = ["fwd", "bwd_query", "cell_count", "scan", "cell_fill", "pull", "fwd_generic", "bwd_generic"]
 for dbg in sys.argv[1:] or ["0"]:
-    os.environ["TRANSOAR_DBG"] = dbg
+    if dbg != "0": os.environ["TRANSOAR_DBG"] = dbg
     for _ in range(2): MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
     torch.cuda.synchronize()
     _native.profile_enable(True)

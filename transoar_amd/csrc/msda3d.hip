@@ -258,13 +258,18 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
                      at, go, gl, ga, fold_count ? count : nullptr, rank, static_cast<int>(cells_per_slab), \
                      d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
-  if (q_order.enabled && fold_count && d.C == 64 && d.P == 4 && sizeof(VT) == 2 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
-    ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
-    const long n_wg = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M;
-    hipLaunchKernelGGL((msda3d_bwd_query_brick<VT, LT, 4, 64>), dim3(((n_wg + 7) / 8) * 8), dim3(kBrickThreads),
-                       kTileBytes, st, v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M,
-                       d.L, n_wg, q_order);
-  } else {
+  bool brick_done = false;
+  if constexpr (sizeof(VT) == 2) {
+    if (q_order.enabled && fold_count && d.C == 64 && d.P == 4 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
+      ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+      const long n_wg = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M;
+      hipLaunchKernelGGL((msda3d_bwd_query_brick<VT, LT, 4, 64>), dim3(((n_wg + 7) / 8) * 8), dim3(kBrickThreads),
+                         kTileBytes, st, v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M,
+                         d.L, n_wg, q_order);
+      brick_done = true;
+    }
+  }
+  if (!brick_done) {
     ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
     if (lg == 3) TRANSOAR_BWDQ(3);
     else if (lg == 4) TRANSOAR_BWDQ(4);

@@ -22,7 +22,8 @@
 
 namespace transoar {
 
-constexpr int kBrickThreads = 256;            // 128 queries x 2 channel halves
+constexpr int kBrickThreads = 256;
+constexpr int kHistCells = 1024;              // LDS counters of the binning pass (cells of one level's box)            // 128 queries x 2 channel halves
 constexpr int kTileBytes = 48 * 1024;         // LDS per workgroup -> 3 workgroups per CU
 
 template <typename VT> struct BrickTraits {
@@ -184,19 +185,20 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_fwd_brick(
 // writes the point's 4 gradients.  Also does the binning pass of the
 // grad_value point sort (one int atomic per point, see msda3d_scatter.hpp).
 // ---------------------------------------------------------------------------
+// both operands stay in their packed 16-bit storage form: 4 two-element dot instructions per
+// 16 bytes (products exact, fp32 accumulation) instead of 8 unpacks + 8 multiply-adds
 template <typename VT, int NV>
-__device__ __forceinline__ typename Elem<VT>::acc dot_row(const u32x4* __restrict__ src,
-                                                          const typename Elem<VT>::acc (&go)[NV * Elem<VT>::VEC]) {
-  constexpr int VEC = Elem<VT>::VEC;
-  typename Elem<VT>::acc d = 0;
+__device__ __forceinline__ float dot_row(const u32x4* __restrict__ src, const u32x4 (&go)[NV]) {
+  float d0 = 0.f, d1 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    typename Elem<VT>::acc v[VEC];
-    Elem<VT>::unpack(src[i], v);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) d += go[i * VEC + e] * v[e];
+    const u32x4 v = src[i];
+    d0 = Elem<VT>::dot2(v[0], go[i][0], d0);
+    d1 = Elem<VT>::dot2(v[1], go[i][1], d1);
+    d0 = Elem<VT>::dot2(v[2], go[i][2], d0);
+    d1 = Elem<VT>::dot2(v[3], go[i][3], d1);
   }
-  return d;
+  return d0 + d1;
 }
 
 template <typename VT, typename LT, int P, int C>
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
   constexpr int TILE_ROWS = kTileBytes / PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   __shared__ int box[6];
+  __shared__ int hist[kHistCells];
 
   const long wg = xcd_contiguous_block(blockIdx.x, n_wg);
   if (wg < 0) return;
@@ -232,15 +235,11 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
   const long row_stride = static_cast<long>(M) * C;
   const VT* vhead = value + (b * S * M + m) * C + half * CPT;
 
-  A go[CPT];
+  u32x4 go[NV];                 // the query's grad_out half-row, packed as stored
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    A v[VEC];
-    u32x4 raw = {0u, 0u, 0u, 0u};
-    if (live) raw = reinterpret_cast<const u32x4*>(grad_out + item * C + half * CPT)[i];
-    Elem<VT>::unpack(raw, v);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) go[i * VEC + e] = v[e];
+    go[i] = u32x4{0u, 0u, 0u, 0u};
+    if (live) go[i] = reinterpret_cast<const u32x4*>(grad_out + item * C + half * CPT)[i];
   }
 
   int cell_start = 0;
@@ -270,17 +269,13 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
           lo_d = min(lo_d, max(d0[p], 0)); hi_d = max(hi_d, min(d0[p] + 1, D - 1));
           lo_h = min(lo_h, max(h0[p], 0)); hi_h = max(hi_h, min(h0[p] + 1, H - 1));
           lo_w = min(lo_w, max(w0[p], 0)); hi_w = max(hi_w, min(w0[p] + 1, W - 1));
-          if (half == 0 && bin_count != nullptr) {
-            // the returned rank is only stored after the sampling loop: its latency hides there
-            const int cell = cell_start + ((d0[p] + 1) * (H + 1) + (h0[p] + 1)) * (W + 1) + (w0[p] + 1);
-            rank[p] = atomicAdd(bin_count + static_cast<int>(b * M + m) * cells_per_slab + cell, 1);
-          }
         }
       }
     }
-    cell_start += (D + 1) * (H + 1) * (W + 1);
     if (tid < 3) box[tid] = 1 << 30;
     else if (tid < 6) box[tid] = -1;
+#pragma unroll
+    for (int i = 0; i < kHistCells / kBrickThreads; ++i) hist[tid + i * kBrickThreads] = 0;
     __syncthreads();
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -298,6 +293,47 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
     const bool any = box[3] >= 0;
     const int rows = TD * TH * TW;
     const bool staged = any && rows <= TILE_ROWS;
+
+    // Binning pass of the grad_value point sort: rank of every point inside its cell.  The
+    // points of this workgroup are first counted per cell in LDS (cells of the box: floor+1 on
+    // each axis spans one more than the voxel box), then ONE global atomic per touched cell
+    // reserves the workgroup's range -- a coarse cell receives thousands of points per slab,
+    // and one returning atomic per point on such a hot counter costs as much as the rest of
+    // this kernel.  The global atomics are in flight while the tile is staged.
+    int* slab_count = bin_count == nullptr ? nullptr : bin_count + static_cast<int>(b * M + m) * cells_per_slab + cell_start;
+    const int CH = TH + 1, CW = TW + 1;
+    const int ncells = (TD + 1) * CH * CW;
+    const bool use_hist = any && ncells <= kHistCells;
+    int lcell[P], cell_base[kHistCells / kBrickThreads];
+    if (slab_count != nullptr && half == 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        lcell[p] = 0;
+        if (!ok[p]) continue;
+        if (use_hist) {
+          lcell[p] = ((d0[p] + 1 - bd) * CH + (h0[p] + 1 - bh)) * CW + (w0[p] + 1 - bw);
+          rank[p] = atomicAdd(&hist[lcell[p]], 1);
+        } else {
+          rank[p] = atomicAdd(slab_count + ((d0[p] + 1) * (H + 1) + (h0[p] + 1)) * (W + 1) + (w0[p] + 1), 1);
+        }
+      }
+    }
+    if (slab_count != nullptr && use_hist) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kHistCells / kBrickThreads; ++i) {
+        const int c = tid + i * kBrickThreads;
+        cell_base[i] = 0;
+        const int n = c < ncells ? hist[c] : 0;
+        if (n > 0) {
+          const int cd = c / (CH * CW), cr = c - cd * (CH * CW);
+          const int ch = cr / CW, cw = cr - ch * CW;
+          cell_base[i] = atomicAdd(slab_count + ((bd + cd) * (H + 1) + (bh + ch)) * (W + 1) + (bw + cw), n);
+        }
+      }
+    }
+    cell_start += (D + 1) * (H + 1) * (W + 1);
+
     if (staged) {
       const int THW = TH * TW;
       for (int i = tid; i < rows * ROW_VECS; i += kBrickThreads) {
@@ -308,7 +344,19 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
         *reinterpret_cast<u32x4*>(tile + r * PITCH + v * 16) =
             *reinterpret_cast<const u32x4*>(value + ((b * S + grow) * M + m) * C + v * VEC);
       }
-      __syncthreads();
+    }
+    if (slab_count != nullptr && use_hist) {
+#pragma unroll
+      for (int i = 0; i < kHistCells / kBrickThreads; ++i) {
+        const int c = tid + i * kBrickThreads;
+        if (c < ncells) hist[c] = cell_base[i];
+      }
+    }
+    __syncthreads();          // tile staged, cell bases published
+    if (slab_count != nullptr && use_hist && half == 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (ok[p]) rank[p] += hist[lcell[p]];
     }
     A res_loc[3 * P], res_attn[P];     // this level's outputs of the query: 48 + 16 contiguous bytes
 #pragma unroll

@@ -89,6 +89,11 @@ template <> struct Elem<bf16_t> {
              (static_cast<unsigned int>(f32_to_bf16(o[2 * i + 1])) << 16);
     return r;
   }
+  // acc + a.lo*b.lo + a.hi*b.hi on two packed pairs, fp32 accumulate (v_dot2c_f32_bf16)
+  static __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float acc) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  }
 };
 
 template <> struct Elem<f16_t> {
@@ -114,6 +119,10 @@ template <> struct Elem<f16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = f2h(o[2 * i]) | (f2h(o[2 * i + 1]) << 16);
     return r;
+  }
+  static __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float acc) {   // v_dot2_f32_f16
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
   }
 };
 

@@ -28,24 +28,23 @@ _DT = {torch.float32: _native.F32, torch.float64: _native.F64,
 flags = 0
 
 
-# host copies of spatial_shapes tensors, keyed on the tensor's storage: the reference passes
-# the level shapes as a device tensor only; one .tolist() (a sync) per distinct tensor buys the
-# brick schedule of the kernels.  locality_hint = False skips it (schedule only, same results).
+# host copy of a spatial_shapes tensor, kept ON the tensor object (it dies with it; an address-keyed
+# cache would hand a recycled allocation the shapes of a dead tensor): the reference passes the level
+# shapes as a device tensor only; one .tolist() (a sync) per distinct tensor buys the brick schedule
+# of the kernels.  locality_hint = False skips it; the per-brick kernels then fall back to the
+# per-item ones (same results).
 locality_hint = True
-_host_shapes = {}
 
 
 def _shapes_on_host(spatial_shapes):
     if not locality_hint:
         return None, None
-    key = (spatial_shapes.data_ptr(), spatial_shapes.device, spatial_shapes._version, tuple(spatial_shapes.shape))
-    hit = _host_shapes.get(key)
-    if hit is None:
-        if len(_host_shapes) > 64:
-            _host_shapes.clear()
-        arr = (ctypes.c_int64 * spatial_shapes.numel())(*[int(v) for v in spatial_shapes.flatten().tolist()])
-        hit = _host_shapes[key] = arr
-    return hit, ctypes.addressof(hit)
+    hit = getattr(spatial_shapes, "_transoar_host_shapes", None)
+    if hit is None or hit[0] != spatial_shapes._version:
+        vals = [int(v) for v in spatial_shapes.flatten().tolist()]
+        hit = (spatial_shapes._version, (ctypes.c_int64 * len(vals))(*vals))
+        spatial_shapes._transoar_host_shapes = hit
+    return hit[1], ctypes.addressof(hit[1])
 
 
 def _require(cond, msg):
