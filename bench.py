@@ -44,29 +44,39 @@ if os.path.isdir(_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
-    """Bytes one launch must move if every tensor is touched once (DESIGN.md)."""
+def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc, fine=None):
+    """Bytes one launch must move if every tensor is touched once (DESIGN.md section 4)."""
     value, out = e * N * S * M * C, e * N * Lq * M * C
     loc_attn = e_loc * N * Lq * M * L * P * 4
+    points = N * Lq * M * L * P
+    recs = points * (32 + 4)                                  # sorted 8-weight record + grad_out row index
+    fine = L if fine is None else fine                        # levels accumulated per brick in LDS (the rest: chunked walk)
     return {
         "fwd": value + out + loc_attn,                       # SURVEY 8d B_fwd
-        "bwd_query": value + out + 2 * loc_attn,             # value, grad_out in; grad_loc/attn out
-        "pull": out + value + loc_attn,                      # grad_out in, grad_value out, point geometry
-        "cell_count": loc_attn, "cell_fill": loc_attn, "scan": 0,
+        "bwd_query": value + out + 2 * loc_attn + 4 * points,    # value, grad_out in; grad_loc/attn + ranks out
+        "pull": out + value + loc_attn,                      # fallback: grad_out in, grad_value out, point geometry
+        # fine levels: every sorted point + its grad_out row once, grad_value rows out.  The figure is
+        # for the whole pyramid (the coarse levels' share of points is in value_cells), split by level:
+        "value_tile": (recs + out) * fine // L + value,
+        "value_cells": (recs + out) * (L - fine) // L,
+        "cell_count": loc_attn, "cell_fill": loc_attn + recs, "scan": 0,
     }.get(kind, 0)
 
 
+PMC_FILE = "r01_msda_pmc_v3.json"
+
+
 def pmc_traffic(kind, dims):
-    """HBM bytes per launch from the committed PMC collection (profiles/r01_msda_pmc.json:
+    """HBM bytes per launch from the committed PMC collection (profiles/<PMC_FILE>:
     FETCH_SIZE/WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied), valid only
     for the shape it was collected on; None otherwise."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         sh = pmc["shape"]
         same = all(sh[k] == dims[k] for k in ("N", "S", "M", "C", "L", "Lq", "P")) and \
             sh["value_dtype"] == ("bf16" if dims["e"] == 2 else "f32")
-        name = {"fwd": "fwd_vec", "bwd_query": "bwd_query_vec", "pull": "value_pull",
-                "cell_count": "cell_count", "cell_fill": "cell_fill"}[kind]
+        name = {"fwd": "fwd_brick", "bwd_query": "bwd_query_brick", "value_tile": "bwd_value_tile",
+                "value_cells": "bwd_value_cells", "cell_fill": "cell_fill_w8"}[kind]
         return round(pmc["kernels"][name]["hbm_bytes_per_launch"] / 1e6, 1) if same else None
     except Exception:
         return None
@@ -209,7 +219,8 @@ def main():
         # MSDeformAttn problem of the refine block at this geometry
         shapes = [(40, 40, 64), (20, 20, 32), (10, 10, 16), (5, 5, 8)]
         S = sum(d * h * w for d, h, w in shapes)
-        dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4)
+        fine = sum(1 for d, h, w in shapes if S * 4 < 128 * d * h * w)     # the dispatch rule of msda3d.hip
+        dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4, fine=fine)
         kernels = {}
         for kind, (ms, n) in prof.items():
             if n == 0:
@@ -226,7 +237,7 @@ def main():
             kd = kernels[dom]
             roofline = {"kernel": "msda3d_" + dom, "bound": "hbm", "achieved": kd["achieved_GBps"],
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kd["achieved_GBps"] / HBM_PEAK_GBPS, 4),
-                        "traffic": pmc_traffic(dom, dims), "traffic_unit": "MB per launch (PMC, profiles/r01_msda_pmc.json)",
+                        "traffic": pmc_traffic(dom, dims), "traffic_unit": "MB per launch (PMC, profiles/%s)" % PMC_FILE,
                         "avg_launch_ms": kd["avg_ms"], "algorithmic_MB": kd["algorithmic_MB"],
                         "timing": "hipEvent pairs on the launch stream, " + (
                             "timed steps" if step_mode == "eager" or step_mode.startswith("eager") else

@@ -68,7 +68,7 @@ enum {
 
 /* flags (bit set) */
 #define TRANSOAR_MSDA3D_FORCE_GENERIC 1u  /* skip the vectorised kernels   */
-#define TRANSOAR_MSDA3D_NO_BRICK 4u        /* forward: per-item kernel even where the LDS-tiled one applies */
+#define TRANSOAR_MSDA3D_NO_BRICK 4u        /* per-item / voxel-stationary kernels even where the LDS-tiled ones apply */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*
@@ -83,9 +83,10 @@ enum {
  *               bf16 autocast produces).
  * host_spatial_shapes: optional HOST copy of spatial_shapes (L*3 int64) or
  *               NULL.  The reference passes the shapes as a device tensor only;
- *               when the host also knows them the kernels walk the work in
- *               4x4x8-voxel bricks for L2 locality.  A schedule hint: results
- *               are identical with NULL.
+ *               when the host also knows them the work is cut into 4x4x8-voxel
+ *               bricks whose value rows / gradient rows live in LDS (16-bit
+ *               storage, C = 64).  Must equal the device tensor.  With NULL the
+ *               per-item kernels run: same results up to summation order.
  * Replaces ms_deform_attn_forward (ops/src/ms_deform_attn.h:20-39).
  */
 int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
@@ -105,8 +106,9 @@ int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
  * `workspace` is a 16-byte aligned device scratch buffer of at least
  * transoar_msda3d_backward_workspace_bytes(...) bytes (same dims, dtypes and
  * flags); it holds the sampling points sorted by cell, from which grad_value
- * is gathered without atomics.  Its contents are dead after the call's
- * kernels have run on `stream`.
+ * is accumulated brick by brick in LDS (fp32 row atomics into a scratch copy
+ * only for pyramid levels with hundreds of points per voxel).  Its contents
+ * are dead after the call's kernels have run on `stream`.
  * Replaces ms_deform_attn_backward (ops/src/ms_deform_attn.h:41-61).
  */
 int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
@@ -136,15 +138,17 @@ size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C,
  * overwritten) and forgets them.  Returns 0 or a hipError_t.
  */
 enum {
-  TRANSOAR_PROF_FWD = 0,          /* msda3d_fwd_vec                     */
-  TRANSOAR_PROF_BWD_QUERY = 1,    /* msda3d_bwd_query_vec               */
+  TRANSOAR_PROF_FWD = 0,          /* msda3d_fwd_brick / msda3d_fwd_vec  */
+  TRANSOAR_PROF_BWD_QUERY = 1,    /* msda3d_bwd_query_brick / _vec      */
   TRANSOAR_PROF_CELL_COUNT = 2,   /* msda3d_cell_count                  */
   TRANSOAR_PROF_SCAN = 3,         /* the three msda3d_scan_* launches   */
-  TRANSOAR_PROF_CELL_FILL = 4,    /* msda3d_cell_fill                   */
-  TRANSOAR_PROF_PULL = 5,         /* msda3d_bwd_value_pull              */
+  TRANSOAR_PROF_CELL_FILL = 4,    /* msda3d_cell_fill / _fill_w8        */
+  TRANSOAR_PROF_PULL = 5,         /* msda3d_bwd_value_pull (voxel-stationary fallback) */
   TRANSOAR_PROF_FWD_GENERIC = 6,
   TRANSOAR_PROF_BWD_GENERIC = 7,
-  TRANSOAR_PROF_KINDS = 8
+  TRANSOAR_PROF_VALUE_TILE = 8,   /* msda3d_bwd_value_tile (+ msda3d_coarse_rows_store) */
+  TRANSOAR_PROF_VALUE_CELLS = 9,  /* scratch memset + msda3d_bwd_value_cells             */
+  TRANSOAR_PROF_KINDS = 10
 };
 void transoar_msda3d_profile_enable(int on);
 int transoar_msda3d_profile_read(double* total_ms, long* launches);

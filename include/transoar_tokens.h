@@ -1,0 +1,65 @@
+/*
+ * transoar_tokens.h -- C ABI of the fused token-stream kernels of the FPN
+ * "refine" block for gfx950: residual add + LayerNorm + the casts and the
+ * positional add that surround it, one pass over the (N*S, C) token matrix
+ * instead of six.
+ *
+ * Replaces, per DefAttnLayer (transoar/models/backbones/decoder_blocks.py:143-177):
+ *     src = norm(src + dropout(branch))                  :167-168 / :172-174
+ * and the head of the next layer / MSDeformAttn input casts under autocast
+ *     query = src + pos  (with_pos_embed, :157-158, :164), pos = sine + level_embed[l] (:76-83)
+ *
+ *   x        (rows, cols) residual stream, fp32 or bf16      rows = N*S tokens
+ *   r        (rows, cols) bf16 branch output (after dropout), or NULL
+ *   y32      (rows, cols) fp32   LayerNorm output (what autocast's layer_norm returns)
+ *   y16      (rows, cols) bf16   the same, rounded: what the next nn.Linear reads
+ *   q16      (rows, cols) bf16   round(y32 + (pos_sine[s] + level_embed[l(s)])), or NULL
+ *   pos_sine (S, cols) fp32, shared by the batch; level_embed (L, cols) fp32;
+ *   level_start (L) int32 first token of each level, S = tokens per batch element
+ *   mean_rstd (rows, 2) fp32 written by forward, read by backward
+ * cols must be a multiple of 128 and <= 1024.  Device pointers, 16-byte
+ * aligned, asynchronous on `hip_stream`.  Returns 0, a hipError_t (> 0) or a
+ * negative code.
+ */
+#ifndef TRANSOAR_TOKENS_H
+#define TRANSOAR_TOKENS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  TRANSOAR_TOK_OK = 0,
+  TRANSOAR_TOK_ERR_NULL = -1,
+  TRANSOAR_TOK_ERR_DIM = -2,
+  TRANSOAR_TOK_ERR_LEVELS = -3
+};
+#define TRANSOAR_TOK_MAX_LEVELS 8
+
+int transoar_add_layernorm_forward(const void* x, int x_is_bf16, const void* r, const float* weight,
+                                   const float* bias, float eps, const float* pos_sine,
+                                   const float* level_embed, const int* level_start, int L, long S,
+                                   float* y32, void* y16, void* q16, float* mean_rstd, long rows,
+                                   int cols, void* hip_stream);
+
+/*
+ * Backward.  g32 / g16 / gq16 are the gradients w.r.t. y32 / y16 / q16 (any of
+ * them may be NULL = zero).  Writes gx (dtype of x) and, when x is fp32, also
+ * gr16 = bf16(gx) for the branch (with a bf16 x the caller uses gx for both).
+ * partials: (transoar_add_layernorm_partial_rows(), (2 + L) * cols) fp32, written
+ * completely: per persistent wave the column sums of g*xhat (-> d weight), g (-> d bias)
+ * and, per level, of gq (-> d level_embed); the caller sums over dim 0.
+ */
+int transoar_add_layernorm_backward(const float* g32, const void* g16, const void* gq16, const void* x,
+                                    int x_is_bf16, const void* r, const float* weight,
+                                    const float* mean_rstd, const int* level_start, int L, long S,
+                                    void* gx, void* gr16, float* partials, long rows, int cols,
+                                    void* hip_stream);
+int transoar_add_layernorm_partial_rows(void);
+
+int transoar_tokens_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSOAR_TOKENS_H */

@@ -1,0 +1,73 @@
+"""Fused residual-add + LayerNorm (+ casts, + positional query) against the stock torch chain."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stock(x, r, norm, pos_sine, level_embed, level_of_token):
+    s = x.float() + (0 if r is None else r.float())
+    y32 = torch.nn.functional.layer_norm(s, (x.shape[-1],), norm.weight.float(), norm.bias.float(), norm.eps)
+    y16 = y32.to(torch.bfloat16)
+    q16 = None
+    if pos_sine is not None:
+        q16 = (y32 + (pos_sine + level_embed[level_of_token])).to(torch.bfloat16)
+    return y32, y16, q16
+
+
+@pytest.mark.parametrize("cols", [128, 384, 1024])
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_r,with_q", [(True, True), (True, False), (False, True)])
+def test_add_layernorm_forward_backward(cols, x_dtype, with_r, with_q):
+    from transoar_amd import tokens
+    torch.manual_seed(0)
+    n, sizes = 2, [700, 90, 13]
+    s_tok = sum(sizes)
+    dev = "cuda"
+    norm = torch.nn.LayerNorm(cols).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.5, 0.5)
+    x0 = (torch.randn(n, s_tok, cols, device=dev) * 2 + 0.3).to(x_dtype)
+    r0 = torch.randn(n, s_tok, cols, device=dev).to(torch.bfloat16) if with_r else None
+    pos_sine = torch.randn(s_tok, cols, device=dev) if with_q else None
+    le0 = torch.randn(len(sizes), cols, device=dev) if with_q else None
+    lot = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.as_tensor(sizes, device=dev))
+    starts = torch.tensor([0, sizes[0], sizes[0] + sizes[1]], dtype=torch.int32, device=dev)
+    g32 = torch.randn(n, s_tok, cols, device=dev)
+    g16 = torch.randn(n, s_tok, cols, device=dev).to(torch.bfloat16)
+    gq = torch.randn(n, s_tok, cols, device=dev).to(torch.bfloat16)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        r = None if r0 is None else r0.clone().requires_grad_(True)
+        le = None if le0 is None else le0.clone().requires_grad_(True)
+        norm.zero_grad()
+        if fused:
+            y32, y16, q16 = tokens.add_layernorm(x, r, norm, *((pos_sine, le, starts) if with_q else ()))
+        else:
+            y32, y16, q16 = _stock(x, r, norm, pos_sine, le, lot)
+        loss = (y32 * g32).sum() + (y16.float() * g16.float()).sum()
+        if with_q:
+            loss = loss + (q16.float() * gq.float()).sum()
+        loss.backward()
+        return (y32, y16, q16, x.grad, None if r is None else r.grad, norm.weight.grad.clone(), norm.bias.grad.clone(),
+                None if le is None else le.grad)
+
+    a, b = run(True), run(False)
+    names = ["y32", "y16", "q16", "gx", "gr", "gw", "gb", "g_level_embed"]
+    for name, u, v in zip(names, a, b):
+        if v is None:
+            assert u is None or name == "q16", name
+            continue
+        assert u.dtype == v.dtype, name
+        u, v = u.double(), v.double()
+        scale = v.abs().max().clamp_min(1e-30)
+        tol = 2.0 ** -7 if a[names.index(name)].dtype == torch.bfloat16 else 2e-5
+        if name in ("gw", "gb", "g_level_embed"):
+            tol = 1e-4          # long column sums, different summation order
+        assert float((u - v).abs().max() / scale) <= tol, (name, float((u - v).abs().max() / scale))
+
+
+def test_rejects_bad_width():
+    from transoar_amd import tokens
+    assert not tokens.usable(torch.zeros(2, 4, 100, device="cuda"), None, 100)

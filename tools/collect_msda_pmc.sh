@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect hardware counters for the MSDeformAttn-3D kernels on the flagship shape.
+# Run on the GPU box from the repo root:   bash tools/collect_msda_pmc.sh <out_dir>
+# One rocprofv3 pass per counter set (gfx950 slot limits: TCC 4, SQ 8, GRBM 2;
+# FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2) -- and never together with the
+# sys/hip/hsa trace domains.  tools/pmc_summary.py turns the CSVs into the JSON
+# committed under profiles/.
+set -u
+OUT=${1:-gpurun_out/msda_pmc}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+CMD="python tools/bench_msda.py --iters 2 --dists model --dtypes bf16"
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+  i=$((i + 1))
+  rocprofv3 --kernel-trace --pmc $SET -f csv -d "$OUT/pass$i" -o p -- $CMD > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
+  # keep only what the summary needs (the box returns at most 64 MiB)
+  find "$OUT/pass$i" -name '*kernel_trace.csv' -delete
+done
+python tools/pmc_summary.py "$OUT" > "$OUT/summary.json"
+ls -la "$OUT"

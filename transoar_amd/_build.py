@@ -20,6 +20,7 @@ LIBS = {
     "libtransoar_conv3d.so": ["conv3d.hip"],
     "libtransoar_instnorm.so": ["instnorm.hip"],
     "libtransoar_rows.so": ["rows.hip"],
+    "libtransoar_tokens.so": ["tokens.hip"],
 }
 
 

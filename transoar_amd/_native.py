@@ -18,7 +18,7 @@ _LIB_NAME = "libtransoar_msda3d.so"
 
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FORCE_GENERIC = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NativeLibraryError(ImportError):
@@ -68,7 +68,8 @@ def check(code, what):
             what, lib.transoar_msda3d_strerror(code).decode(), code))
 
 
-PROF_KINDS = ("fwd", "bwd_query", "cell_count", "scan", "cell_fill", "pull", "fwd_generic", "bwd_generic")
+PROF_KINDS = ("fwd", "bwd_query", "cell_count", "scan", "cell_fill", "pull", "fwd_generic", "bwd_generic",
+              "value_tile", "value_cells")
 
 
 def profile_enable(on):

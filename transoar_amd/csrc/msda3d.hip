@@ -303,7 +303,6 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
                            rank, recs8, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
       }
-      ProfScope prof(TRANSOAR_PROF_PULL, st);
       // levels where a cell holds >= 128 points on average go to the chunked walk
       CoarseLevels cl{d.L, static_cast<int>(cells_per_slab), d.S, 0, 0};
       for (int l = d.L - 1; l >= 0; --l) {
@@ -320,12 +319,14 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       float* scratch = reinterpret_cast<float*>(ws + w.coarse);
       const long scratch_elems = static_cast<long>(d.N) * cl.rows * d.M * kTileC;
       if (coarse_levels > 0) {
+        ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, st);
         TRANSOAR_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * scratch_elems, st));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
         hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, st,
                            go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl,
                            r_order);
       }
+      ProfScope prof(TRANSOAR_PROF_VALUE_TILE, st);
       if (fine_bricks > 0) {
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
         hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
@@ -491,4 +492,4 @@ extern "C" int transoar_msda3d_profile_read(double* total_ms, long* launches) {
   return rc;
 }
 
-extern "C" int transoar_msda3d_abi_version(void) { return 4; }
+extern "C" int transoar_msda3d_abi_version(void) { return 5; }

@@ -1,0 +1,257 @@
+// Fused residual-add + LayerNorm (+ casts, + positional add) over the token
+// stream of the refine block; C ABI in include/transoar_tokens.h.  gfx950 only.
+//
+// One wave per token row: cols = 128*K columns, lane l holds columns
+// i*128 + 2l, +1 (i < K) -> every load/store of a row is one contiguous
+// 512-byte (fp32) or 256-byte (bf16) wave access.  Statistics are two-pass in
+// registers (mean, then centred second moment), fp32.  HBM-bound by design:
+// forward moves 18 B/element (fp32 stream) where the unfused chain moves 48.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_tokens.h"
+
+namespace {
+
+constexpr int kWaves = 4;                       // rows per workgroup
+constexpr int kPersistentWaves = 256 * 2 * kWaves;   // backward: 2 workgroups per CU
+
+__device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+  return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// row of the residual stream (+ branch) into registers
+template <int K, bool XBF>
+__device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, long row, int cols, int lane,
+                                         float (&v)[2 * K]) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const long e = row * cols + i * 128 + 2 * lane;
+    float a, b;
+    if (XBF) {
+      const unsigned int u = static_cast<const unsigned int*>(x)[e >> 1];
+      a = bf16_lo(u); b = bf16_hi(u);
+    } else {
+      const float2 f = *reinterpret_cast<const float2*>(static_cast<const float*>(x) + e);
+      a = f.x; b = f.y;
+    }
+    if (r != nullptr) {
+      const unsigned int u = r[e >> 1];
+      a += bf16_lo(u); b += bf16_hi(u);
+    }
+    v[2 * i] = a; v[2 * i + 1] = b;
+  }
+}
+
+__device__ __forceinline__ int level_of(const int* level_start, int L, int s) {
+  int l = 0;
+  for (int t = 1; t < L; ++t) l += (s >= level_start[t]) ? 1 : 0;
+  return l;
+}
+
+template <int K, bool XBF>
+__global__ __launch_bounds__(64 * kWaves) void add_ln_fwd(
+    const void* __restrict__ x, const unsigned int* __restrict__ r, const float* __restrict__ weight,
+    const float* __restrict__ bias, float eps, const float* __restrict__ pos_sine,
+    const float* __restrict__ level_embed, const int* __restrict__ level_start, int L, long S,
+    float* __restrict__ y32, unsigned int* __restrict__ y16, unsigned int* __restrict__ q16,
+    float* __restrict__ mean_rstd, long rows) {
+  constexpr int cols = 128 * K;
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[2 * K];
+  load_sum<K, XBF>(x, r, row, cols, lane, v);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2 * K; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.0f / cols);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2 * K; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / cols) + eps);
+  if (lane == 0) *reinterpret_cast<float2*>(mean_rstd + 2 * row) = float2{mean, rstd};
+  const long srow = row % S;
+  const int lvl = q16 != nullptr ? level_of(level_start, L, static_cast<int>(srow)) : 0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int c = i * 128 + 2 * lane;
+    const float2 w = *reinterpret_cast<const float2*>(weight + c), b = *reinterpret_cast<const float2*>(bias + c);
+    const float y0 = v[2 * i] * rstd * w.x + b.x, y1 = v[2 * i + 1] * rstd * w.y + b.y;
+    const long e = row * cols + c;
+    *reinterpret_cast<float2*>(y32 + e) = float2{y0, y1};
+    y16[e >> 1] = pack_bf16(y0, y1);
+    if (q16 != nullptr) {
+      const float2 ps = *reinterpret_cast<const float2*>(pos_sine + srow * cols + c);
+      const float2 le = *reinterpret_cast<const float2*>(level_embed + lvl * cols + c);
+      q16[e >> 1] = pack_bf16(y0 + (ps.x + le.x), y1 + (ps.y + le.y));
+    }
+  }
+}
+
+template <int K, bool XBF>
+__global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
+    const float* __restrict__ g32, const unsigned int* __restrict__ g16, const unsigned int* __restrict__ gq16,
+    const void* __restrict__ x, const unsigned int* __restrict__ r, const float* __restrict__ weight,
+    const float* __restrict__ mean_rstd, const int* __restrict__ level_start, int L, long S,
+    void* __restrict__ gx, unsigned int* __restrict__ gr16, float* __restrict__ partials, long rows) {
+  constexpr int cols = 128 * K;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  float w[2 * K], dw[2 * K], db[2 * K];
+  float dle[TRANSOAR_TOK_MAX_LEVELS][2 * K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const float2 f = *reinterpret_cast<const float2*>(weight + i * 128 + 2 * lane);
+    w[2 * i] = f.x; w[2 * i + 1] = f.y;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * K; ++i) dw[i] = db[i] = 0.f;
+#pragma unroll
+  for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) dle[l][i] = 0.f;
+
+  for (long row = wave; row < rows; row += kPersistentWaves) {
+    float v[2 * K], g[2 * K];
+    load_sum<K, XBF>(x, r, row, cols, lane, v);
+    const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + 2 * row);
+    const int lvl = gq16 != nullptr ? level_of(level_start, L, static_cast<int>(row % S)) : 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const long e = row * cols + i * 128 + 2 * lane;
+      float a = 0.f, b = 0.f;
+      if (g32 != nullptr) {
+        const float2 f = *reinterpret_cast<const float2*>(g32 + e);
+        a = f.x; b = f.y;
+      }
+      if (g16 != nullptr) {
+        const unsigned int u = g16[e >> 1];
+        a += bf16_lo(u); b += bf16_hi(u);
+      }
+      if (gq16 != nullptr) {
+        const unsigned int u = gq16[e >> 1];
+        const float qa = bf16_lo(u), qb = bf16_hi(u);
+        a += qa; b += qb;
+        // uniform level per row: a switch keeps dle[] in registers
+#pragma unroll
+        for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
+          if (l == lvl) { dle[l][2 * i] += qa; dle[l][2 * i + 1] += qb; }
+      }
+      g[2 * i] = a; g[2 * i + 1] = b;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) {
+      v[i] = (v[i] - mr.x) * mr.y;                 // xhat
+      db[i] += g[i];
+      dw[i] += g[i] * v[i];
+      g[i] *= w[i];
+      s1 += g[i];
+      s2 += g[i] * v[i];
+    }
+    s1 = wave_sum(s1) * (1.0f / cols);
+    s2 = wave_sum(s2) * (1.0f / cols);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const long e = row * cols + i * 128 + 2 * lane;
+      const float d0 = (g[2 * i] - s1 - v[2 * i] * s2) * mr.y, d1 = (g[2 * i + 1] - s1 - v[2 * i + 1] * s2) * mr.y;
+      if (XBF) {
+        static_cast<unsigned int*>(gx)[e >> 1] = pack_bf16(d0, d1);
+      } else {
+        *reinterpret_cast<float2*>(static_cast<float*>(gx) + e) = float2{d0, d1};
+        if (gr16 != nullptr) gr16[e >> 1] = pack_bf16(d0, d1);
+      }
+    }
+  }
+  float* out = partials + static_cast<long>(wave) * (2 + L) * cols;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int c = i * 128 + 2 * lane;
+    *reinterpret_cast<float2*>(out + c) = float2{dw[2 * i], dw[2 * i + 1]};
+    *reinterpret_cast<float2*>(out + cols + c) = float2{db[2 * i], db[2 * i + 1]};
+#pragma unroll
+    for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
+      if (l < L) *reinterpret_cast<float2*>(out + (2 + l) * cols + c) = float2{dle[l][2 * i], dle[l][2 * i + 1]};
+  }
+}
+
+}  // namespace
+
+#define TOK_DISPATCH(K_, BODY) \
+  switch (K_) {                \
+    case 1: { constexpr int K = 1; BODY; break; } \
+    case 2: { constexpr int K = 2; BODY; break; } \
+    case 3: { constexpr int K = 3; BODY; break; } \
+    case 4: { constexpr int K = 4; BODY; break; } \
+    case 6: { constexpr int K = 6; BODY; break; } \
+    case 8: { constexpr int K = 8; BODY; break; } \
+    default: return TRANSOAR_TOK_ERR_DIM;         \
+  }
+
+extern "C" int transoar_add_layernorm_forward(const void* x, int x_is_bf16, const void* r, const float* weight,
+                                              const float* bias, float eps, const float* pos_sine,
+                                              const float* level_embed, const int* level_start, int L, long S,
+                                              float* y32, void* y16, void* q16, float* mean_rstd, long rows,
+                                              int cols, void* hip_stream) {
+  if (!x || !weight || !bias || !y32 || !y16 || !mean_rstd) return TRANSOAR_TOK_ERR_NULL;
+  if (q16 && (!pos_sine || !level_embed || !level_start)) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
+  if (L < 0 || L > TRANSOAR_TOK_MAX_LEVELS || (q16 && L == 0)) return TRANSOAR_TOK_ERR_LEVELS;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(static_cast<unsigned>((rows + kWaves - 1) / kWaves)), block(64 * kWaves);
+  auto rr = static_cast<const unsigned int*>(r);
+  auto o16 = static_cast<unsigned int*>(y16);
+  auto oq = static_cast<unsigned int*>(q16);
+  TOK_DISPATCH(cols / 128, {
+    if (x_is_bf16)
+      hipLaunchKernelGGL((add_ln_fwd<K, true>), grid, block, 0, st, x, rr, weight, bias, eps, pos_sine, level_embed,
+                         level_start, L, S, y32, o16, oq, mean_rstd, rows);
+    else
+      hipLaunchKernelGGL((add_ln_fwd<K, false>), grid, block, 0, st, x, rr, weight, bias, eps, pos_sine, level_embed,
+                         level_start, L, S, y32, o16, oq, mean_rstd, rows);
+  });
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16, const void* gq16, const void* x,
+                                               int x_is_bf16, const void* r, const float* weight,
+                                               const float* mean_rstd, const int* level_start, int L, long S,
+                                               void* gx, void* gr16, float* partials, long rows, int cols,
+                                               void* hip_stream) {
+  if (!x || !weight || !mean_rstd || !gx || !partials) return TRANSOAR_TOK_ERR_NULL;
+  if (gq16 && !level_start) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
+  if (L < 0 || L > TRANSOAR_TOK_MAX_LEVELS) return TRANSOAR_TOK_ERR_LEVELS;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(kPersistentWaves / kWaves), block(64 * kWaves);
+  auto a16 = static_cast<const unsigned int*>(g16);
+  auto aq = static_cast<const unsigned int*>(gq16);
+  auto rr = static_cast<const unsigned int*>(r);
+  auto o16 = static_cast<unsigned int*>(gr16);
+  TOK_DISPATCH(cols / 128, {
+    if (x_is_bf16)
+      hipLaunchKernelGGL((add_ln_bwd<K, true>), grid, block, 0, st, g32, a16, aq, x, rr, weight, mean_rstd,
+                         level_start, L, S, gx, o16, partials, rows);
+    else
+      hipLaunchKernelGGL((add_ln_bwd<K, false>), grid, block, 0, st, g32, a16, aq, x, rr, weight, mean_rstd,
+                         level_start, L, S, gx, o16, partials, rows);
+  });
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
+extern "C" int transoar_tokens_abi_version(void) { return 1; }

@@ -17,6 +17,7 @@ from torch import nn
 
 from .ms_deform_attn import MSDeformAttn
 from .token_linear import token_linear
+from . import tokens as fused_tokens
 
 
 class _MapToTokens(torch.autograd.Function):
@@ -84,6 +85,17 @@ class DefAttnLayer(nn.Module):
         hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
         ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ffn))
+
+    def forward_fused(self, x, x16, q16, reference_points, spatial_shapes, level_start_index, pos_pack=()):
+        """Same layer on the fused token kernels (transoar_amd/tokens.py), bf16 autocast on the GPU.
+        x: residual stream (fp32, or the bf16 backbone tokens for the first layer); x16 / q16: its
+        bf16 rounding and the bf16 query round(x + pos).  pos_pack = (pos_sine, level_embed,
+        level_start) asks for the next layer's query.  -> (y32, y16, q16 or None)"""
+        attn = self.self_attn(q16, reference_points, x16, spatial_shapes, level_start_index)
+        y32, y16, _ = fused_tokens.add_layernorm(x, self.dropout1(attn), self.norm1)
+        hidden = self.dropout2(self.activation(token_linear(y16, self.linear1.weight, self.linear1.bias)))
+        ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
+        return fused_tokens.add_layernorm(y32, self.dropout3(ffn), self.norm2, *pos_pack)
 
 
 class DefAttnTransformer(nn.Module):
@@ -156,10 +168,41 @@ class DecoderDefAttnBlock(nn.Module):
         spatial, starts, sizes, ref = self._level_geometry(shapes, fmaps[0].device)
         # token-major (N, S, C), contiguous: what the projections and the kernels read
         tokens = torch.cat([map_to_tokens(f) for f in fmaps], dim=1)
-        pos = torch.cat([self._pos_tokens(p, lvl) + self.level_embed[lvl].view(1, 1, -1).to(p.dtype)
-                         for lvl, p in enumerate(pos_embeds)], dim=1)
-        memory = self.refine_def_attn(tokens, spatial, starts, pos, ref)
+        if self._fused_ok(tokens, pos_embeds):
+            memory = self._forward_fused(tokens, pos_embeds, shapes, spatial, starts, sizes, ref)
+        else:
+            pos = torch.cat([self._pos_tokens(p, lvl) + self.level_embed[lvl].view(1, 1, -1).to(p.dtype)
+                             for lvl, p in enumerate(pos_embeds)], dim=1)
+            memory = self.refine_def_attn(tokens, spatial, starts, pos, ref)
         return [tokens_to_map(m.contiguous(), shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
+
+    def _fused_ok(self, tokens, pos_embeds):
+        return (tokens.is_cuda and tokens.dtype == torch.bfloat16 and tokens.is_contiguous()
+                and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and not any(p.requires_grad for p in pos_embeds)
+                and fused_tokens.usable(tokens, None, self.d_model))
+
+    def _forward_fused(self, tokens, pos_embeds, shapes, spatial, starts, sizes, ref):
+        """The layer stack on the fused token kernels: the residual stream stays fp32 (what autocast's
+        layer_norm returns), its bf16 rounding and the next layer's bf16 query come out of the same pass."""
+        key = ("pos_sine", shapes, tokens.device)
+        const = self._geometry.get(key)
+        if const is None:
+            # the sine encoding does not depend on the batch element or the input
+            sine = torch.cat([self._pos_tokens(p, lvl)[0] for lvl, p in enumerate(pos_embeds)], dim=0)
+            const = self._geometry[key] = (sine.float().contiguous(), starts.int().contiguous())
+        pos_sine, starts32 = const
+        pos_pack = (pos_sine, self.level_embed, starts32)
+        layers = self.refine_def_attn.layers
+        # first layer: query = round(tokens + pos) the stock way (one pass over the bf16 tokens)
+        # (expand + cat, not level_embed[level_of_token]: an indexed gather's backward is a sort-based index_put)
+        level_pos = torch.cat([self.level_embed[l].to(pos_sine.dtype).expand(n_l, -1) for l, n_l in enumerate(sizes)], 0)
+        q16 = (tokens + (pos_sine + level_pos)).to(torch.bfloat16)
+        x, x16 = tokens, tokens
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            x, x16, q16 = layer.forward_fused(x, x16, q16, ref, spatial, starts, () if last else pos_pack)
+        return x
 
     def _pos_tokens(self, pos_map, lvl):
         """(N, C, D, H, W) positional map -> (N, V, C) tokens; the sine encoding

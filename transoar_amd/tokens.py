@@ -1,0 +1,115 @@
+"""Autograd shim of the fused residual-add + LayerNorm kernels
+(include/transoar_tokens.h) for the token stream of the refine block.
+
+``add_layernorm(x, r, norm, ...)`` returns what the reference's
+``norm(x + r)`` returns under autocast (fp32) TOGETHER with its bf16 rounding
+(what the next nn.Linear would cast it to) and, optionally, the bf16 query of the
+next layer ``round(y + (pos_sine + level_embed[level]))`` -- one pass over the
+tokens instead of add, layer_norm, two casts, the positional add and its cast.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _native  # noqa: F401
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libtransoar_tokens.so")
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise _native.NativeLibraryError("%s is not built (python transoar_amd/_build.py)" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    i, p, lg, f = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
+    lib.transoar_add_layernorm_forward.restype = i
+    lib.transoar_add_layernorm_forward.argtypes = [p, i, p, p, p, f, p, p, p, i, lg, p, p, p, p, lg, i, p]
+    lib.transoar_add_layernorm_backward.restype = i
+    lib.transoar_add_layernorm_backward.argtypes = [p, p, p, p, i, p, p, p, p, i, lg, p, p, p, lg, i, p]
+    lib.transoar_add_layernorm_partial_rows.restype = i
+    lib.transoar_tokens_abi_version.restype = i
+    if lib.transoar_tokens_abi_version() != 1:
+        raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
+    return lib
+
+
+lib = _load()
+PARTIAL_ROWS = lib.transoar_add_layernorm_partial_rows()
+
+
+def usable(x, r, cols):
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+            and (r is None or (r.dtype == torch.bfloat16 and r.is_contiguous() and r.shape == x.shape))
+            and cols % 128 == 0 and cols // 128 in (1, 2, 3, 4, 6, 8))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(x, r, weight, bias, pos_sine, level_embed, level_start) -> (y32, y16, q16)"""
+
+    @staticmethod
+    def forward(ctx, x, r, weight, bias, eps, pos_sine, level_embed, level_start):
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        with_q = pos_sine is not None
+        w32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        q16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if with_q else None
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        n_lvl = level_embed.shape[0] if with_q else 0
+        s_tokens = pos_sine.shape[0] if with_q else rows
+        le32 = level_embed.float().contiguous() if with_q else None
+        with torch.cuda.device(x.device):
+            rc = lib.transoar_add_layernorm_forward(
+                x.data_ptr(), int(x.dtype == torch.bfloat16), _ptr(r), w32.data_ptr(), b32.data_ptr(), float(eps),
+                _ptr(pos_sine), _ptr(le32), _ptr(level_start), n_lvl, s_tokens, y32.data_ptr(), y16.data_ptr(),
+                _ptr(q16), stats.data_ptr(), rows, cols, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_add_layernorm_forward failed with code %d" % rc)
+        ctx.save_for_backward(x, r, w32, stats, level_start)
+        ctx.n_lvl, ctx.s_tokens, ctx.with_q = n_lvl, s_tokens, with_q
+        ctx.param_dtype = weight.dtype
+        ctx.le_dtype = level_embed.dtype if with_q else None
+        return y32, y16, q16
+
+    @staticmethod
+    def backward(ctx, g32, g16, gq16):
+        x, r, w32, stats, level_start = ctx.saved_tensors
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        g32 = None if g32 is None else g32.contiguous()
+        g16 = None if g16 is None else g16.contiguous()
+        gq16 = None if (gq16 is None or not ctx.with_q) else gq16.contiguous()
+        x_bf16 = x.dtype == torch.bfloat16
+        gx = torch.empty_like(x)
+        gr = None
+        if r is not None and ctx.needs_input_grad[1] and not x_bf16:
+            gr = torch.empty_like(r)
+        n_lvl = ctx.n_lvl if gq16 is not None else 0
+        partials = torch.empty((PARTIAL_ROWS, 2 + n_lvl, cols), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.transoar_add_layernorm_backward(
+                _ptr(g32), _ptr(g16), _ptr(gq16), x.data_ptr(), int(x_bf16), _ptr(r), w32.data_ptr(),
+                stats.data_ptr(), _ptr(level_start), n_lvl, ctx.s_tokens, gx.data_ptr(), _ptr(gr),
+                partials.data_ptr(), rows, cols, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_add_layernorm_backward failed with code %d" % rc)
+        sums = partials.sum(0)
+        g_le = None
+        if ctx.with_q and ctx.needs_input_grad[6]:
+            g_le = (sums[2:] if n_lvl else torch.zeros(ctx.n_lvl, cols, device=x.device)).to(ctx.le_dtype)
+        if r is not None and x_bf16:
+            gr = gx
+        return (gx, gr, sums[0].to(ctx.param_dtype), sums[1].to(ctx.param_dtype), None, None, g_le, None)
+
+
+def add_layernorm(x, r, norm, pos_sine=None, level_embed=None, level_start=None):
+    """-> (y32, y16, q16 or None).  x (..., C) fp32/bf16 residual stream, r bf16 branch or None,
+    norm an nn.LayerNorm over C.  With pos_sine (S, C) fp32 (no grad), level_embed (L, C) and
+    level_start (L,) int32, q16 = bf16(y + (pos_sine[s] + level_embed[level(s)]))."""
+    return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, pos_sine, level_embed, level_start)
