@@ -64,7 +64,7 @@ int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N,
 
 /*
  * First layer, Cin == 1, stride 1: stencil.
- *   x (N, D, H, W) bf16 ; w (27, Cout) fp32 ; y (N, D, H, W, Cout) bf16
+ *   x (N, D, H, W) bf16 ; w (27, Cout) fp32 ; y (N, D, H, W, Cout) bf16 ; Cout % 8 == 0, Cout <= 64
  */
 int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H,
                                int W, int Cout, void* hip_stream);

@@ -318,14 +318,21 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad(const unsigned short* __r
 // One thread per output voxel: its 27 inputs sit in registers, the weights are
 // wave-uniform (scalar loads), output channels are produced 8 at a time.
 // ---------------------------------------------------------------------------
+constexpr int kC1MaxCout = 64;
 __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __restrict__ x,
                                                      const float* __restrict__ w,
                                                      unsigned short* __restrict__ y, int N, int D, int H,
                                                      int W, int Cout, long n_vox) {
-  const long v = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (v >= n_vox) return;
-  const int ow = static_cast<int>(v % W);
-  const long r1 = v / W;
+  // the 256 voxels of a workgroup are consecutive rows of y: their Cout-channel rows are staged in
+  // LDS in the global order and leave as whole 16-byte-per-lane contiguous stores (a thread writing
+  // its own row scatters 16-byte pieces at a Cout*2-byte stride: 400 GB/s measured on the 630 MB output)
+  __shared__ u32x4c stage[256 * kC1MaxCout / 8];
+  const long v0 = static_cast<long>(blockIdx.x) * 256;
+  const long v = v0 + threadIdx.x;
+  const bool live = v < n_vox;
+  const long vc = live ? v : n_vox - 1;
+  const int ow = static_cast<int>(vc % W);
+  const long r1 = vc / W;
   const int oh = static_cast<int>(r1 % H);
   const long r2 = r1 / H;
   const int od = static_cast<int>(r2 % D);
@@ -341,8 +348,13 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __res
         const bool ok = static_cast<unsigned>(id) < static_cast<unsigned>(D) &&
                         static_cast<unsigned>(ih) < static_cast<unsigned>(H) &&
                         static_cast<unsigned>(iw) < static_cast<unsigned>(W);
-        xv[kd * 9 + kh * 3 + kw] = ok ? bf2f(x[((nbase + id) * H + ih) * W + iw]) : 0.f;
+        // branch-free: a clamped (always valid) address, then a select -- under a divergent branch
+        // each of the 27 loads waits for its own round trip
+        const int cd = min(max(id, 0), D - 1), chh = min(max(ih, 0), H - 1), cw = min(max(iw, 0), W - 1);
+        const float val = bf2f(x[((nbase + cd) * H + chh) * W + cw]);
+        xv[kd * 9 + kh * 3 + kw] = ok ? val : 0.f;
       }
+  const int cpv = Cout >> 3;                  // 16-byte chunks per voxel row
   for (int c0 = 0; c0 < Cout; c0 += 8) {      // uniform loop: weights come through the scalar cache
     float acc[8];
 #pragma unroll
@@ -357,8 +369,12 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       pk[e] = static_cast<unsigned>(f2bf(acc[2 * e])) | (static_cast<unsigned>(f2bf(acc[2 * e + 1])) << 16);
-    *reinterpret_cast<u32x4c*>(y + v * Cout + c0) = pk;
+    stage[threadIdx.x * cpv + (c0 >> 3)] = pk;
   }
+  __syncthreads();
+  const long chunks = min(static_cast<long>(256), n_vox - v0) * cpv;
+  u32x4c* dst = reinterpret_cast<u32x4c*>(y + v0 * Cout);
+  for (int i = threadIdx.x; i < chunks; i += 256) dst[i] = stage[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -479,7 +495,7 @@ extern "C" int transoar_conv3d_c1_forward(const void* x, const float* w, void* y
                                           int Cout, void* hip_stream) {
   if (!x || !w || !y) return TRANSOAR_CONV_ERR_NULL;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return TRANSOAR_CONV_ERR_DIM;
-  if (Cout & 7) return TRANSOAR_CONV_ERR_CHANNELS;
+  if ((Cout & 7) || Cout > transoar::kC1MaxCout) return TRANSOAR_CONV_ERR_CHANNELS;
   const long n_vox = static_cast<long>(N) * D * H * W;
   hipLaunchKernelGGL(conv3d_c1_fwd, dim3(static_cast<unsigned>((n_vox + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(x), w,
