@@ -16,6 +16,8 @@
  *   q16      (rows, cols) bf16   round(y32 + (pos_sine[s] + level_embed[l(s)])), or NULL
  *   pos_sine (S, cols) fp32, shared by the batch; level_embed (L, cols) fp32;
  *   level_start (L) int32 first token of each level, S = tokens per batch element
+ *   keep     (rows, cols) mask bytes of the branch's dropout (r is the branch BEFORE dropout:
+ *            the kernels apply keep ? r * keep_scale : 0), or NULL when r is already final
  *   mean_rstd (rows, 2) fp32 written by forward, read by backward
  * cols must be a multiple of 128 and <= 1024.  Device pointers, 16-byte
  * aligned, asynchronous on `hip_stream`.  Returns 0, a hipError_t (> 0) or a
@@ -40,12 +42,14 @@ int transoar_add_layernorm_forward(const void* x, int x_is_bf16, const void* r, 
                                    const float* bias, float eps, const float* pos_sine,
                                    const float* level_embed, const int* level_start, int L, long S,
                                    float* y32, void* y16, void* q16, float* mean_rstd, long rows,
-                                   int cols, void* hip_stream);
+                                   int cols, const unsigned char* keep, float keep_scale,
+                                   void* hip_stream);
 
 /*
  * Backward.  g32 / g16 / gq16 are the gradients w.r.t. y32 / y16 / q16 (any of
- * them may be NULL = zero).  Writes gx (dtype of x) and, when x is fp32, also
- * gr16 = bf16(gx) for the branch (with a bf16 x the caller uses gx for both).
+ * them may be NULL = zero).  Writes gx (dtype of x) and, when gr16 is given, the
+ * branch gradient gr16 = bf16(keep ? gx * keep_scale : 0)  (without a mask and with a
+ * bf16 x the caller may use gx for both and pass NULL).
  * partials: (transoar_add_layernorm_partial_rows(), (2 + L) * cols) fp32, written
  * completely: per persistent wave the column sums of g*xhat (-> d weight), g (-> d bias)
  * and, per level, of gq (-> d level_embed); the caller sums over dim 0.
@@ -54,7 +58,18 @@ int transoar_add_layernorm_backward(const float* g32, const void* g16, const voi
                                     int x_is_bf16, const void* r, const float* weight,
                                     const float* mean_rstd, const int* level_start, int L, long S,
                                     void* gx, void* gr16, float* partials, long rows, int cols,
-                                    void* hip_stream);
+                                    const unsigned char* keep, float keep_scale, void* hip_stream);
+
+/*
+ * FFN activation of the layer, one pass each way (decoder_blocks.py:171-172,
+ * dropout2(activation(linear1(src))) with activation = relu), bf16, n % 8 == 0:
+ *   y  = keep ? relu(h) * keep_scale : 0        keep: n mask bytes, NULL = keep all
+ *   gh = y > 0 ? gy * keep_scale : 0            (y > 0  <=>  kept and h > 0)
+ */
+int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale, void* y,
+                                  long n, void* hip_stream);
+int transoar_relu_dropout_backward(const void* gy, const void* y, float keep_scale, void* gh, long n,
+                                   void* hip_stream);
 int transoar_add_layernorm_partial_rows(void);
 
 int transoar_tokens_abi_version(void);

@@ -71,3 +71,49 @@ def test_add_layernorm_forward_backward(cols, x_dtype, with_r, with_q):
 def test_rejects_bad_width():
     from transoar_amd import tokens
     assert not tokens.usable(torch.zeros(2, 4, 100, device="cuda"), None, 100)
+
+
+def test_dropout_inside_add_layernorm_and_relu_dropout():
+    """With an active nn.Dropout the kernels apply the byte mask themselves: same result as the
+    stock chain fed the same mask, forward and backward."""
+    from transoar_amd import tokens
+    torch.manual_seed(1)
+    dev, cols, rows = "cuda", 384, 1000
+    norm = torch.nn.LayerNorm(cols).to(dev)
+    x0 = torch.randn(1, rows, cols, device=dev)
+    r0 = torch.randn(1, rows, cols, device=dev).to(torch.bfloat16)
+    keep = tokens.dropout_mask(r0, 0.1)
+    frac = keep.float().mean().item()
+    assert 0.88 < frac < 0.92
+    scale = 1.0 / 0.9
+    g = torch.randn(1, rows, cols, device=dev)
+    res = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True); r = r0.clone().requires_grad_(True)
+        norm.zero_grad()
+        if fused:
+            y32, y16, _ = tokens._AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, None, None, None, keep, scale)
+        else:
+            y32 = torch.nn.functional.layer_norm(x + (r.float() * keep * scale), (cols,), norm.weight, norm.bias, norm.eps)
+        (y32 * g).sum().backward()
+        res.append((y32, x.grad, r.grad))
+    for u, v in zip(*res):
+        tol = 2.0 ** -7 if u.dtype == torch.bfloat16 else 2e-5
+        assert u.dtype == v.dtype
+        assert float((u.double() - v.double()).abs().max() / v.double().abs().max()) <= tol
+    # relu + dropout
+    h0 = torch.randn(rows, 1024, device=dev).to(torch.bfloat16)
+    keep2 = tokens.dropout_mask(h0, 0.1)
+    gy = torch.randn(rows, 1024, device=dev).to(torch.bfloat16)
+    h = h0.clone().requires_grad_(True)
+    y = tokens._ReluDropout.apply(h, keep2, scale)
+    y.backward(gy)
+    h2 = h0.clone().requires_grad_(True)
+    y2 = (torch.relu(h2).float() * keep2 * scale).to(torch.bfloat16)
+    y2.backward(gy)
+    assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -7 * float(y2.float().abs().max())
+    assert float((h.grad.float() - h2.grad.float()).abs().max()) <= 2.0 ** -7 * float(h2.grad.float().abs().max())
+    # inactive dropout: exact relu
+    drop = torch.nn.Dropout(0.1).eval()
+    assert torch.equal(tokens.relu_dropout(h0, drop), torch.relu(h0))
+

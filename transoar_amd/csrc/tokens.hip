@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int kWaves = 4;                       // rows per workgroup
-constexpr int kPersistentWaves = 256 * 2 * kWaves;   // backward: 2 workgroups per CU
+constexpr int kPersistentWaves = 256 * 4 * kWaves;   // backward: 4 workgroups per CU (16 waves: the row walk is latency-bound)
 
 __device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
@@ -34,9 +34,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // row of the residual stream (+ branch) into registers
+// (the branch r may still need its dropout: keep[e] != 0 -> r[e] * scale, else 0)
 template <int K, bool XBF>
-__device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, long row, int cols, int lane,
-                                         float (&v)[2 * K]) {
+__device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, const unsigned short* keep, float scale,
+                                         long row, int cols, int lane, float (&v)[2 * K],
+                                         unsigned short (&mask)[K]) {
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const long e = row * cols + i * 128 + 2 * lane;
@@ -50,7 +52,15 @@ __device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, l
     }
     if (r != nullptr) {
       const unsigned int u = r[e >> 1];
-      a += bf16_lo(u); b += bf16_hi(u);
+      float ra = bf16_lo(u), rb = bf16_hi(u);
+      mask[i] = 0x0101;
+      if (keep != nullptr) {
+        const unsigned short m = keep[e >> 1];          // two mask bytes
+        mask[i] = m;
+        ra = (m & 0xffu) ? ra * scale : 0.f;
+        rb = (m >> 8) ? rb * scale : 0.f;
+      }
+      a += ra; b += rb;
     }
     v[2 * i] = a; v[2 * i + 1] = b;
   }
@@ -68,13 +78,14 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_fwd(
     const float* __restrict__ bias, float eps, const float* __restrict__ pos_sine,
     const float* __restrict__ level_embed, const int* __restrict__ level_start, int L, long S,
     float* __restrict__ y32, unsigned int* __restrict__ y16, unsigned int* __restrict__ q16,
-    float* __restrict__ mean_rstd, long rows) {
+    float* __restrict__ mean_rstd, long rows, const unsigned short* __restrict__ keep, float scale) {
   constexpr int cols = 128 * K;
   const int lane = threadIdx.x & 63;
   const long row = static_cast<long>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
   float v[2 * K];
-  load_sum<K, XBF>(x, r, row, cols, lane, v);
+  unsigned short mask[K];
+  load_sum<K, XBF>(x, r, keep, scale, row, cols, lane, v, mask);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 2 * K; ++i) s += v[i];
@@ -107,7 +118,8 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
     const float* __restrict__ g32, const unsigned int* __restrict__ g16, const unsigned int* __restrict__ gq16,
     const void* __restrict__ x, const unsigned int* __restrict__ r, const float* __restrict__ weight,
     const float* __restrict__ mean_rstd, const int* __restrict__ level_start, int L, long S,
-    void* __restrict__ gx, unsigned int* __restrict__ gr16, float* __restrict__ partials, long rows) {
+    void* __restrict__ gx, unsigned int* __restrict__ gr16, float* __restrict__ partials, long rows,
+    const unsigned short* __restrict__ keep, float scale) {
   constexpr int cols = 128 * K;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -127,7 +139,8 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
 
   for (long row = wave; row < rows; row += kPersistentWaves) {
     float v[2 * K], g[2 * K];
-    load_sum<K, XBF>(x, r, row, cols, lane, v);
+    unsigned short mask[K];
+    load_sum<K, XBF>(x, r, keep, scale, row, cols, lane, v, mask);
     const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + 2 * row);
     const int lvl = gq16 != nullptr ? level_of(level_start, L, static_cast<int>(row % S)) : 0;
 #pragma unroll
@@ -173,7 +186,14 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
         static_cast<unsigned int*>(gx)[e >> 1] = pack_bf16(d0, d1);
       } else {
         *reinterpret_cast<float2*>(static_cast<float*>(gx) + e) = float2{d0, d1};
-        if (gr16 != nullptr) gr16[e >> 1] = pack_bf16(d0, d1);
+      }
+      if (gr16 != nullptr) {                      // gradient of the (pre-dropout) branch
+        float r0 = d0, r1 = d1;
+        if (keep != nullptr) {
+          r0 = (mask[i] & 0xffu) ? d0 * scale : 0.f;
+          r1 = (mask[i] >> 8) ? d1 * scale : 0.f;
+        }
+        gr16[e >> 1] = pack_bf16(r0, r1);
       }
     }
   }
@@ -187,6 +207,38 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
     for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
       if (l < L) *reinterpret_cast<float2*>(out + (2 + l) * cols + c) = float2{dle[l][2 * i], dle[l][2 * i + 1]};
   }
+}
+
+// y = keep ? relu(h) * scale : 0 on bf16, 8 elements per thread
+__global__ __launch_bounds__(256) void relu_dropout_fwd(const uint4* __restrict__ h, const uint2* __restrict__ keep,
+                                                        float scale, uint4* __restrict__ y, long n8) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 u = h[i];
+  const uint2 m = keep != nullptr ? keep[i] : uint2{0x01010101u, 0x01010101u};
+  const unsigned int in[4] = {u.x, u.y, u.z, u.w};
+  unsigned int out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned int mb = (j < 2 ? m.x : m.y) >> (16 * (j & 1));
+    const float a = fmaxf(bf16_lo(in[j]), 0.f), b = fmaxf(bf16_hi(in[j]), 0.f);
+    out[j] = pack_bf16((mb & 0xffu) ? a * scale : 0.f, (mb & 0xff00u) ? b * scale : 0.f);
+  }
+  y[i] = uint4{out[0], out[1], out[2], out[3]};
+}
+// gh = y > 0 ? gy * scale : 0   (y > 0 <=> kept and h > 0)
+__global__ __launch_bounds__(256) void relu_dropout_bwd(const uint4* __restrict__ gy, const uint4* __restrict__ y,
+                                                        float scale, uint4* __restrict__ gh, long n8) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 g = gy[i], o = y[i];
+  const unsigned int gi[4] = {g.x, g.y, g.z, g.w}, oi[4] = {o.x, o.y, o.z, o.w};
+  unsigned int out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    out[j] = pack_bf16(bf16_lo(oi[j]) > 0.f ? bf16_lo(gi[j]) * scale : 0.f,
+                       bf16_hi(oi[j]) > 0.f ? bf16_hi(gi[j]) * scale : 0.f);
+  gh[i] = uint4{out[0], out[1], out[2], out[3]};
 }
 
 }  // namespace
@@ -206,7 +258,8 @@ extern "C" int transoar_add_layernorm_forward(const void* x, int x_is_bf16, cons
                                               const float* bias, float eps, const float* pos_sine,
                                               const float* level_embed, const int* level_start, int L, long S,
                                               float* y32, void* y16, void* q16, float* mean_rstd, long rows,
-                                              int cols, void* hip_stream) {
+                                              int cols, const unsigned char* keep, float keep_scale,
+                                              void* hip_stream) {
   if (!x || !weight || !bias || !y32 || !y16 || !mean_rstd) return TRANSOAR_TOK_ERR_NULL;
   if (q16 && (!pos_sine || !level_embed || !level_start)) return TRANSOAR_TOK_ERR_NULL;
   if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
@@ -216,13 +269,14 @@ extern "C" int transoar_add_layernorm_forward(const void* x, int x_is_bf16, cons
   auto rr = static_cast<const unsigned int*>(r);
   auto o16 = static_cast<unsigned int*>(y16);
   auto oq = static_cast<unsigned int*>(q16);
+  auto kp = reinterpret_cast<const unsigned short*>(keep);
   TOK_DISPATCH(cols / 128, {
     if (x_is_bf16)
       hipLaunchKernelGGL((add_ln_fwd<K, true>), grid, block, 0, st, x, rr, weight, bias, eps, pos_sine, level_embed,
-                         level_start, L, S, y32, o16, oq, mean_rstd, rows);
+                         level_start, L, S, y32, o16, oq, mean_rstd, rows, kp, keep_scale);
     else
       hipLaunchKernelGGL((add_ln_fwd<K, false>), grid, block, 0, st, x, rr, weight, bias, eps, pos_sine, level_embed,
-                         level_start, L, S, y32, o16, oq, mean_rstd, rows);
+                         level_start, L, S, y32, o16, oq, mean_rstd, rows, kp, keep_scale);
   });
   return static_cast<int>(hipGetLastError());
 }
@@ -231,7 +285,7 @@ extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16
                                                int x_is_bf16, const void* r, const float* weight,
                                                const float* mean_rstd, const int* level_start, int L, long S,
                                                void* gx, void* gr16, float* partials, long rows, int cols,
-                                               void* hip_stream) {
+                                               const unsigned char* keep, float keep_scale, void* hip_stream) {
   if (!x || !weight || !mean_rstd || !gx || !partials) return TRANSOAR_TOK_ERR_NULL;
   if (gq16 && !level_start) return TRANSOAR_TOK_ERR_NULL;
   if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
@@ -242,16 +296,39 @@ extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16
   auto aq = static_cast<const unsigned int*>(gq16);
   auto rr = static_cast<const unsigned int*>(r);
   auto o16 = static_cast<unsigned int*>(gr16);
+  auto kp = reinterpret_cast<const unsigned short*>(keep);
   TOK_DISPATCH(cols / 128, {
     if (x_is_bf16)
       hipLaunchKernelGGL((add_ln_bwd<K, true>), grid, block, 0, st, g32, a16, aq, x, rr, weight, mean_rstd,
-                         level_start, L, S, gx, o16, partials, rows);
+                         level_start, L, S, gx, o16, partials, rows, kp, keep_scale);
     else
       hipLaunchKernelGGL((add_ln_bwd<K, false>), grid, block, 0, st, g32, a16, aq, x, rr, weight, mean_rstd,
-                         level_start, L, S, gx, o16, partials, rows);
+                         level_start, L, S, gx, o16, partials, rows, kp, keep_scale);
   });
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale, void* y,
+                                             long n, void* hip_stream) {
+  if (!h || !y) return TRANSOAR_TOK_ERR_NULL;
+  if (n <= 0 || (n & 7)) return TRANSOAR_TOK_ERR_DIM;
+  const long n8 = n >> 3;
+  hipLaunchKernelGGL(relu_dropout_fwd, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(h),
+                     reinterpret_cast<const uint2*>(keep), keep_scale, static_cast<uint4*>(y), n8);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_relu_dropout_backward(const void* gy, const void* y, float keep_scale, void* gh, long n,
+                                              void* hip_stream) {
+  if (!gy || !y || !gh) return TRANSOAR_TOK_ERR_NULL;
+  if (n <= 0 || (n & 7)) return TRANSOAR_TOK_ERR_DIM;
+  const long n8 = n >> 3;
+  hipLaunchKernelGGL(relu_dropout_bwd, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(gy), static_cast<const uint4*>(y),
+                     keep_scale, static_cast<uint4*>(gh), n8);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 1; }
+extern "C" int transoar_tokens_abi_version(void) { return 2; }

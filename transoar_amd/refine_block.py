@@ -92,10 +92,14 @@ class DefAttnLayer(nn.Module):
         bf16 rounding and the bf16 query round(x + pos).  pos_pack = (pos_sine, level_embed,
         level_start) asks for the next layer's query.  -> (y32, y16, q16 or None)"""
         attn = self.self_attn(q16, reference_points, x16, spatial_shapes, level_start_index)
-        y32, y16, _ = fused_tokens.add_layernorm(x, self.dropout1(attn), self.norm1)
-        hidden = self.dropout2(self.activation(token_linear(y16, self.linear1.weight, self.linear1.bias)))
+        y32, y16, _ = fused_tokens.add_layernorm(x, attn.contiguous(), self.norm1, dropout=self.dropout1)
+        hidden = token_linear(y16, self.linear1.weight, self.linear1.bias)
+        if self.activation is F.relu and hidden.dtype == torch.bfloat16 and hidden.numel() % 8 == 0:
+            hidden = fused_tokens.relu_dropout(hidden, self.dropout2)
+        else:
+            hidden = self.dropout2(self.activation(hidden))
         ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
-        return fused_tokens.add_layernorm(y32, self.dropout3(ffn), self.norm2, *pos_pack)
+        return fused_tokens.add_layernorm(y32, ffn.contiguous(), self.norm2, *pos_pack, dropout=self.dropout3)
 
 
 class DefAttnTransformer(nn.Module):

@@ -24,12 +24,16 @@ def _load():
     lib = ctypes.CDLL(_LIB_PATH)
     i, p, lg, f = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
     lib.transoar_add_layernorm_forward.restype = i
-    lib.transoar_add_layernorm_forward.argtypes = [p, i, p, p, p, f, p, p, p, i, lg, p, p, p, p, lg, i, p]
+    lib.transoar_add_layernorm_forward.argtypes = [p, i, p, p, p, f, p, p, p, i, lg, p, p, p, p, lg, i, p, f, p]
     lib.transoar_add_layernorm_backward.restype = i
-    lib.transoar_add_layernorm_backward.argtypes = [p, p, p, p, i, p, p, p, p, i, lg, p, p, p, lg, i, p]
+    lib.transoar_add_layernorm_backward.argtypes = [p, p, p, p, i, p, p, p, p, i, lg, p, p, p, lg, i, p, f, p]
+    lib.transoar_relu_dropout_forward.restype = i
+    lib.transoar_relu_dropout_forward.argtypes = [p, p, f, p, lg, p]
+    lib.transoar_relu_dropout_backward.restype = i
+    lib.transoar_relu_dropout_backward.argtypes = [p, p, f, p, lg, p]
     lib.transoar_add_layernorm_partial_rows.restype = i
     lib.transoar_tokens_abi_version.restype = i
-    if lib.transoar_tokens_abi_version() != 1:
+    if lib.transoar_tokens_abi_version() != 2:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -49,10 +53,10 @@ def _ptr(t):
 
 
 class _AddLayerNorm(torch.autograd.Function):
-    """(x, r, weight, bias, pos_sine, level_embed, level_start) -> (y32, y16, q16)"""
+    """(x, r, weight, bias, eps, pos_sine, level_embed, level_start, keep, keep_scale) -> (y32, y16, q16)"""
 
     @staticmethod
-    def forward(ctx, x, r, weight, bias, eps, pos_sine, level_embed, level_start):
+    def forward(ctx, x, r, weight, bias, eps, pos_sine, level_embed, level_start, keep, keep_scale):
         cols = x.shape[-1]
         rows = x.numel() // cols
         with_q = pos_sine is not None
@@ -68,10 +72,12 @@ class _AddLayerNorm(torch.autograd.Function):
             rc = lib.transoar_add_layernorm_forward(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), _ptr(r), w32.data_ptr(), b32.data_ptr(), float(eps),
                 _ptr(pos_sine), _ptr(le32), _ptr(level_start), n_lvl, s_tokens, y32.data_ptr(), y16.data_ptr(),
-                _ptr(q16), stats.data_ptr(), rows, cols, torch.cuda.current_stream().cuda_stream)
+                _ptr(q16), stats.data_ptr(), rows, cols, _ptr(keep), float(keep_scale),
+                torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_add_layernorm_forward failed with code %d" % rc)
-        ctx.save_for_backward(x, r, w32, stats, level_start)
+        ctx.save_for_backward(x, r, w32, stats, level_start, keep)
+        ctx.keep_scale = float(keep_scale)
         ctx.n_lvl, ctx.s_tokens, ctx.with_q = n_lvl, s_tokens, with_q
         ctx.param_dtype = weight.dtype
         ctx.le_dtype = level_embed.dtype if with_q else None
@@ -79,7 +85,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g32, g16, gq16):
-        x, r, w32, stats, level_start = ctx.saved_tensors
+        x, r, w32, stats, level_start, keep = ctx.saved_tensors
         cols = x.shape[-1]
         rows = x.numel() // cols
         g32 = None if g32 is None else g32.contiguous()
@@ -88,7 +94,7 @@ class _AddLayerNorm(torch.autograd.Function):
         x_bf16 = x.dtype == torch.bfloat16
         gx = torch.empty_like(x)
         gr = None
-        if r is not None and ctx.needs_input_grad[1] and not x_bf16:
+        if r is not None and ctx.needs_input_grad[1] and (not x_bf16 or keep is not None):
             gr = torch.empty_like(r)
         n_lvl = ctx.n_lvl if gq16 is not None else 0
         partials = torch.empty((PARTIAL_ROWS, 2 + n_lvl, cols), dtype=torch.float32, device=x.device)
@@ -96,20 +102,66 @@ class _AddLayerNorm(torch.autograd.Function):
             rc = lib.transoar_add_layernorm_backward(
                 _ptr(g32), _ptr(g16), _ptr(gq16), x.data_ptr(), int(x_bf16), _ptr(r), w32.data_ptr(),
                 stats.data_ptr(), _ptr(level_start), n_lvl, ctx.s_tokens, gx.data_ptr(), _ptr(gr),
-                partials.data_ptr(), rows, cols, torch.cuda.current_stream().cuda_stream)
+                partials.data_ptr(), rows, cols, _ptr(keep), ctx.keep_scale, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_add_layernorm_backward failed with code %d" % rc)
         sums = partials.sum(0)
         g_le = None
         if ctx.with_q and ctx.needs_input_grad[6]:
             g_le = (sums[2:] if n_lvl else torch.zeros(ctx.n_lvl, cols, device=x.device)).to(ctx.le_dtype)
-        if r is not None and x_bf16:
+        if r is not None and x_bf16 and keep is None:
             gr = gx
-        return (gx, gr, sums[0].to(ctx.param_dtype), sums[1].to(ctx.param_dtype), None, None, g_le, None)
+        return (gx, gr, sums[0].to(ctx.param_dtype), sums[1].to(ctx.param_dtype), None, None, g_le, None, None, None)
 
 
-def add_layernorm(x, r, norm, pos_sine=None, level_embed=None, level_start=None):
+def dropout_mask(like, p):
+    """Keep-mask bytes (1 = keep) for a dropout of probability p over a tensor shaped like `like`,
+    from torch's generator (capture-safe), or None when nothing is dropped."""
+    if p <= 0.0:
+        return None
+    return torch.empty(like.shape, dtype=torch.uint8, device=like.device).bernoulli_(1.0 - p)
+
+
+def add_layernorm(x, r, norm, pos_sine=None, level_embed=None, level_start=None, dropout=None):
     """-> (y32, y16, q16 or None).  x (..., C) fp32/bf16 residual stream, r bf16 branch or None,
     norm an nn.LayerNorm over C.  With pos_sine (S, C) fp32 (no grad), level_embed (L, C) and
-    level_start (L,) int32, q16 = bf16(y + (pos_sine[s] + level_embed[level(s)]))."""
-    return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, pos_sine, level_embed, level_start)
+    level_start (L,) int32, q16 = bf16(y + (pos_sine[s] + level_embed[level(s)])).
+    dropout: the nn.Dropout that the reference applies to the branch first (applied inside the
+    kernel from a byte mask when it is active)."""
+    keep, scale = None, 1.0
+    if dropout is not None and dropout.training and dropout.p > 0.0 and r is not None:
+        keep, scale = dropout_mask(r, dropout.p), 1.0 / (1.0 - dropout.p)
+    return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, pos_sine, level_embed, level_start, keep, scale)
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, keep, scale):
+        y = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            rc = lib.transoar_relu_dropout_forward(h.data_ptr(), _ptr(keep), float(scale), y.data_ptr(), h.numel(),
+                                                   torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_relu_dropout_forward failed with code %d" % rc)
+        ctx.save_for_backward(y)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gy = gy.contiguous()
+        gh = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = lib.transoar_relu_dropout_backward(gy.data_ptr(), y.data_ptr(), ctx.scale, gh.data_ptr(), y.numel(),
+                                                    torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_relu_dropout_backward failed with code %d" % rc)
+        return gh, None, None
+
+
+def relu_dropout(h, dropout):
+    """dropout(relu(h)) for a contiguous bf16 CUDA tensor (numel % 8 == 0) in one pass each way."""
+    active = dropout.training and dropout.p > 0.0
+    keep = dropout_mask(h, dropout.p) if active else None
+    return _ReluDropout.apply(h, keep, 1.0 / (1.0 - dropout.p) if active else 1.0)
