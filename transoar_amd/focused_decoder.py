@@ -109,6 +109,8 @@ class FocusedAttn(nn.Module):
             k_tok = v_tok + rows.gather(k_pos, flat)
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())
+        if FocusedAttn.fold_projections and self.pos_bias is None and not (self.training and self.attn_drop.p > 0):
+            return self._roi_attention_folded(q, k_tok, v_tok, pad, n_org, n_keys)
         kk = token_linear(k_tok, self.k_proj.weight, self.k_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         vv = token_linear(v_tok, self.v_proj.weight, self.v_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
@@ -125,6 +127,31 @@ class FocusedAttn(nn.Module):
         attn = attn.masked_fill(pad[None, :, None, None, :], float("-inf")).softmax(dim=-1)
         x = self.attn_drop(attn) @ vv                                     # (B, O, h, qpo, hd)
         return x.permute(0, 1, 3, 2, 4).reshape(b, n_q, c)
+
+    # The K and V projections commute with the attention sums:
+    #   score_h(q, k) = q_h . (Wk_h x_k + bk_h) = (Wk_h^T q_h) . x_k + const(q, h)      (const drops out of softmax)
+    #   out_h(q)      = sum_k p_k (Wv_h x_k + bv_h) = Wv_h (sum_k p_k x_k) + bv_h        (sum_k p_k = 1)
+    # so the 27 queries x 8 heads of an organ become 216 rows of ONE plain attention over the organ's raw
+    # tokens (dimension C), two batched GEMMs each way, and neither K nor V (B*O*L x C each, plus their
+    # data and weight gradient GEMMs over 2*10^5 tokens) is ever formed.  Same arithmetic up to association.
+    fold_projections = True
+
+    def _roi_attention_folded(self, q, k_tok, v_tok, pad, n_org, n_keys):
+        b, n_q, c = q.shape
+        qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
+        qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd)                       # sic: k_proj
+        w_k = self.k_proj.weight.view(h, hd, c).to(qq.dtype)
+        qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
+        scores = qf @ k_tok.view(b, n_org, n_keys, c).transpose(-1, -2)                     # (B, O, h*qpo, L)
+        scores = scores.masked_fill(pad[None, :, None, :], float("-inf"))
+        with torch.autocast(q.device.type, enabled=False):
+            prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
+        ctx = (prob @ v_tok.view(b, n_org, n_keys, c)).view(b, n_org, h, qpo, c)            # sum_k p_k x_k
+        w_v = self.v_proj.weight.view(h, hd, c).to(ctx.dtype)
+        out = torch.einsum("bohqc,hdc->boqhd", ctx, w_v)
+        if self.v_proj.bias is not None:
+            out = out + self.v_proj.bias.view(h, hd).to(out.dtype)
+        return out.reshape(b, n_q, c)
 
     def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None):
         """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf; roi: the
