@@ -71,6 +71,27 @@ class _GatherTokens(torch.autograd.Function):
         return gx.to(g.dtype), None, None
 
 
+class _Scores(torch.autograd.Function):
+    """scores = q @ k^T for (…, Q, C) x (…, L, C).  Written out so that the key gradient is produced
+    as ds^T @ q, i.e. directly in the (…, L, C) token layout: autograd's generic rule returns a
+    transposed view whose later .contiguous() is a 170-MB strided copy per layer."""
+
+    @staticmethod
+    def forward(ctx, q, k):
+        ctx.save_for_backward(q, k)
+        return q @ k.transpose(-1, -2)
+
+    @staticmethod
+    def backward(ctx, ds):
+        q, k = ctx.saved_tensors
+        dq = dk = None
+        if ctx.needs_input_grad[0]:
+            dq = ds @ k
+        if ctx.needs_input_grad[1]:
+            dk = ds.transpose(-1, -2) @ q
+        return dq, dk
+
+
 class FocusedAttn(nn.Module):
     def __init__(self, dim, num_heads, attn_mask, qkv_bias=None, qk_scale=None, attn_drop=0,
                  proj_drop=0, use_pos_bias=False, return_weights=True):
@@ -106,7 +127,14 @@ class FocusedAttn(nn.Module):
         if k_pos is None:
             k_tok = v_tok
         elif rows.usable(k_pos) and k_pos.is_contiguous():
-            k_tok = v_tok + rows.gather(k_pos, flat)
+            # the positional tokens are the same tensor for every layer and (sine encoding) every step:
+            # their gathered form is kept on the tensor object, keyed by its version and the index list
+            hit = getattr(k_pos, "_transoar_roi_gather", None) if not k_pos.requires_grad else None
+            if hit is None or hit[0] != (k_pos._version, flat.data_ptr(), flat._version):
+                hit = ((k_pos._version, flat.data_ptr(), flat._version), rows.gather(k_pos, flat))
+                if not k_pos.requires_grad:
+                    k_pos._transoar_roi_gather = hit
+            k_tok = v_tok + hit[1]
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())
         if FocusedAttn.fold_projections and self.pos_bias is None and not (self.training and self.attn_drop.p > 0):
@@ -142,7 +170,7 @@ class FocusedAttn(nn.Module):
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd)                       # sic: k_proj
         w_k = self.k_proj.weight.view(h, hd, c).to(qq.dtype)
         qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
-        scores = qf @ k_tok.view(b, n_org, n_keys, c).transpose(-1, -2)                     # (B, O, h*qpo, L)
+        scores = _Scores.apply(qf, k_tok.view(b, n_org, n_keys, c).to(qf.dtype))             # (B, O, h*qpo, L)
         scores = scores.masked_fill(pad[None, :, None, :], float("-inf"))
         with torch.autocast(q.device.type, enabled=False):
             prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
