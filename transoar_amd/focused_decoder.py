@@ -130,8 +130,9 @@ class FocusedAttn(nn.Module):
             # the positional tokens are the same tensor for every layer and (sine encoding) every step:
             # their gathered form is kept on the tensor object, keyed by its version and the index list
             hit = getattr(k_pos, "_transoar_roi_gather", None) if not k_pos.requires_grad else None
-            if hit is None or hit[0] != (k_pos._version, flat.data_ptr(), flat._version):
-                hit = ((k_pos._version, flat.data_ptr(), flat._version), rows.gather(k_pos, flat))
+            key = (k_pos._version, flat.data_ptr(), flat._version, v_tok.dtype)
+            if hit is None or hit[0] != key:
+                hit = (key, rows.gather(k_pos, flat).to(v_tok.dtype))
                 if not k_pos.requires_grad:
                     k_pos._transoar_roi_gather = hit
             k_tok = v_tok + hit[1]
@@ -320,6 +321,11 @@ class FocusedDecoderModel(nn.Module):
 
     def forward(self, tgt, src, src_pos, query_pos=None):
         out, stack = tgt, []
+        if src.is_cuda and src.dtype == torch.float32 and torch.is_autocast_enabled() \
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            # every consumer of src in the layers is a bf16 GEMM operand under autocast: round it once
+            # for all layers instead of gathering / adding fp32 tokens and casting them per layer
+            src = src.to(torch.bfloat16)
         for layer in self.layers:
             out, _ = layer(out, query_pos, src_pos, src)
             if self.return_intermediate:
