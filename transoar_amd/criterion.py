@@ -60,19 +60,24 @@ class TransoarCriterion(nn.Module):
         per = F.binary_cross_entropy_with_logits(logits, labels.clamp(min=0), reduction="none")
         return (per * valid).sum() / (valid.sum() if n_valid is None else n_valid)
 
-    def loss_bboxes(self, outputs, targets, matches, num_boxes, matches_per_class=1):
+    def bbox_terms(self, outputs, targets):
+        """Per (sample, class, query) L1 and 1-GIoU of the predicted boxes against the class target."""
         preds = outputs["pred_boxes"]
         n, n_q, _ = preds.shape
         qpo = n_q // self.num_classes
         preds = preds.reshape(n, self.num_classes, qpo, -1).float()
-        sel = matches.to(preds.dtype)[..., None]                     # (N, classes, qpo, 1)
         tgt = targets.boxes[:, :, None, :]
-        l1 = ((preds - tgt).abs() * sel).sum()
+        l1 = (preds - tgt).abs().sum(-1)
         giou = elementwise_giou_3d(box_cxcyczwhd_to_xyzxyz(preds.clamp(min=0)), box_cxcyczwhd_to_xyzxyz(tgt))
+        return l1, 1 - giou
+
+    def loss_bboxes(self, outputs, targets, matches, num_boxes, matches_per_class=1, terms=None):
+        l1, one_minus_giou = self.bbox_terms(outputs, targets) if terms is None else terms
+        hit = matches.bool()
+        zero = torch.zeros_like(l1)
         # unmatched entries may hold 0-volume targets -> NaN giou; mask by select, not multiply
-        gl = torch.where(matches.bool(), 1 - giou, torch.zeros_like(giou)).sum()
         denom = num_boxes * matches_per_class
-        return l1 / denom, gl / denom
+        return torch.where(hit, l1, zero).sum() / denom, torch.where(hit, one_minus_giou, zero).sum() / denom
 
     def loss_segmentation(self, outputs, targets):
         if self._seg_fg_bg:
@@ -88,16 +93,22 @@ class TransoarCriterion(nn.Module):
         if targets.n_present is not None:
             qpo = outputs["pred_logits"].shape[1] // self.num_classes
             n_valid = targets.n_present * qpo
-        matches, soft = self.matcher(outputs, targets, anchors)
-        loss_bbox, loss_giou = self.loss_bboxes(outputs, targets, matches, num_boxes)
+        geo = self.matcher.geometry(outputs, targets, anchors)
+        soft = geo[1]
+        matches = self.matcher.assign(outputs["pred_logits"], geo)
+        terms = self.bbox_terms(outputs, targets)      # of the FINAL outputs: the aux terms reuse them (sic, below)
+        loss_bbox, loss_giou = self.loss_bboxes(outputs, targets, matches, num_boxes, terms=terms)
         zero = torch.zeros((), device=outputs["pred_logits"].device)
-        losses = {"bbox": loss_bbox, "giou": loss_giou, "cls": self.loss_class(outputs, soft, n_valid),
-                  "segce": zero, "segdice": zero}
+        loss_cls = self.loss_class(outputs, soft, n_valid)
+        losses = {"bbox": loss_bbox, "giou": loss_giou, "cls": loss_cls, "segce": zero, "segdice": zero}
         if self._seg_proxy:
             losses["segce"], losses["segdice"] = self.loss_segmentation(outputs, seg_targets)
+        shared = self.matcher.anchor_matching      # then geometry and soft labels do not depend on the output
         for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            matches, soft = self.matcher(aux, targets, anchors)
-            lb, lg = self.loss_bboxes(outputs, targets, matches, num_boxes)      # sic: final outputs
+            geo_i = geo if shared else self.matcher.geometry(aux, targets, anchors)
+            matches = self.matcher.assign(aux["pred_logits"], geo_i)
+            lb, lg = self.loss_bboxes(outputs, targets, matches, num_boxes, terms=terms)      # sic: final outputs
             losses["bbox_%d" % i], losses["giou_%d" % i] = lb, lg
-            losses["cls_%d" % i] = self.loss_class(outputs, soft, n_valid)
+            # sic: the class loss of the FINAL logits against this output's soft labels (criterion.py:117-124)
+            losses["cls_%d" % i] = loss_cls if shared else self.loss_class(outputs, geo_i[1], n_valid)
         return losses

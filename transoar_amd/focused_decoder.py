@@ -129,12 +129,17 @@ class FocusedAttn(nn.Module):
         elif rows.usable(k_pos) and k_pos.is_contiguous():
             # the positional tokens are the same tensor for every layer and (sine encoding) every step:
             # their gathered form is kept on the tensor object, keyed by its version and the index list
-            hit = getattr(k_pos, "_transoar_roi_gather", None) if not k_pos.requires_grad else None
+            cache = getattr(k_pos, "_transoar_roi_gather", None) if not k_pos.requires_grad else None
             key = (k_pos._version, flat.data_ptr(), flat._version, v_tok.dtype)
-            if hit is None or hit[0] != key:
+            hit = None if cache is None else cache.get(key)
+            if hit is None:
                 hit = (key, rows.gather(k_pos, flat).to(v_tok.dtype))
                 if not k_pos.requires_grad:
-                    k_pos._transoar_roi_gather = hit
+                    if cache is None:
+                        cache = k_pos._transoar_roi_gather = {}
+                    if len(cache) >= 8:
+                        cache.clear()
+                    cache[key] = hit
             k_tok = v_tok + hit[1]
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())

@@ -54,29 +54,27 @@ class Matcher(nn.Module):
     def forward(self, outputs, targets, anchors, num_top_queries=1):
         """-> matches (N, organs, qpo) long 0/1, soft_labels (N, organs, qpo) float."""
         logits = outputs["pred_logits"]
-        n, n_q, _ = logits.shape
-        qpo = n_q // self.num_organs
         if not isinstance(targets, DenseTargets):
             targets = DenseTargets.from_list(targets, self.num_organs, logits.device)
+        geo = self.geometry(outputs, targets, anchors)
+        return self.assign(logits, geo, num_top_queries), geo[1]
+
+    def geometry(self, outputs, targets, anchors):
+        """The box side of the matching: (cost_giou, soft_labels, boxes, tgt, present).  With
+        anchor matching it depends on the anchors and the targets only -- the criterion computes it
+        once and reuses it for the auxiliary outputs."""
+        logits = outputs["pred_logits"]
+        n, n_q, _ = logits.shape
+        qpo = n_q // self.num_organs
         if self.anchor_matching:
             boxes = anchors[None].expand(n, -1, -1)
         else:
             boxes = outputs["pred_boxes"]
         boxes = boxes.reshape(n, self.num_organs, qpo, -1).float()
-        probs = logits.reshape(n, self.num_organs, qpo).float().sigmoid()
         tgt = targets.boxes[:, :, None, :]                                       # (N, organs, 1, 6)
         present = targets.present[:, :, None]
-
         cost_giou = -elementwise_giou_3d(box_cxcyczwhd_to_xyzxyz(boxes.clamp(min=0)),
                                          box_cxcyczwhd_to_xyzxyz(tgt))
-        cost = self.cost_class * (-probs) + self.cost_giou * cost_giou
-        if self.cost_bbox != 0:
-            cost = cost + self.cost_bbox * (boxes - tgt).abs().sum(-1)
-        best = cost.topk(num_top_queries, dim=-1, largest=False).indices
-        matches = torch.zeros(n, self.num_organs, qpo, dtype=torch.long, device=logits.device)
-        matches.scatter_(-1, best, 1)
-        matches = matches * present
-
         if qpo == 1:     # the reference's TypeError branch (matcher.py:59-61)
             soft = torch.ones_like(cost_giou)
         else:
@@ -84,4 +82,18 @@ class Matcher(nn.Module):
             lo = cost_giou.min(-1, keepdim=True).values
             soft = ((cost_giou - hi) / (lo - hi)).clamp(min=0)
         soft = torch.where(present, soft, torch.full_like(soft, -1.0))
-        return matches, soft
+        return cost_giou, soft, boxes, tgt, present
+
+    def assign(self, logits, geo, num_top_queries=1):
+        """Top-k queries per organ under cost = class + giou (+ bbox) terms -> matches (N, organs, qpo)."""
+        cost_giou, _, boxes, tgt, present = geo
+        n, n_q, _ = logits.shape
+        qpo = n_q // self.num_organs
+        probs = logits.reshape(n, self.num_organs, qpo).float().sigmoid()
+        cost = self.cost_class * (-probs) + self.cost_giou * cost_giou
+        if self.cost_bbox != 0:
+            cost = cost + self.cost_bbox * (boxes - tgt).abs().sum(-1)
+        best = cost.topk(num_top_queries, dim=-1, largest=False).indices
+        matches = torch.zeros(n, self.num_organs, qpo, dtype=torch.long, device=logits.device)
+        matches.scatter_(-1, best, 1)
+        return matches * present
