@@ -219,7 +219,7 @@ def main():
         # MSDeformAttn problem of the refine block at this geometry
         shapes = [(40, 40, 64), (20, 20, 32), (10, 10, 16), (5, 5, 8)]
         S = sum(d * h * w for d, h, w in shapes)
-        fine = sum(1 for d, h, w in shapes if S * 4 < 128 * d * h * w)     # the dispatch rule of msda3d.hip
+        fine = sum(1 for d, h, w in shapes if S * 4 < 32 * d * h * w)      # the dispatch rule of msda3d.hip (kCoarsePointsPerVoxel)
         dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4, fine=fine)
         kernels = {}
         for kind, (ms, n) in prof.items():

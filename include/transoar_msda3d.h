@@ -32,7 +32,9 @@
  *   attn_weight      (N, Lq, M, L, P)
  *   out / grad_out   (N, Lq, M*C)
  * All device buffers must be 16-byte aligned (torch allocations are).
- * Everything is asynchronous on `stream`; no host synchronisation inside.
+ * Everything is asynchronous on `stream`; no host synchronisation inside.  With TRANSOAR_MSDA3D_FORK
+ * the backward forks part of its work onto an internal side stream and joins it back into `stream`
+ * before it returns (graph-capture safe, but slower under graph replay; off by default).
  */
 #ifndef TRANSOAR_MSDA3D_H
 #define TRANSOAR_MSDA3D_H
@@ -69,6 +71,7 @@ enum {
 /* flags (bit set) */
 #define TRANSOAR_MSDA3D_FORCE_GENERIC 1u  /* skip the vectorised kernels   */
 #define TRANSOAR_MSDA3D_NO_BRICK 4u        /* per-item / voxel-stationary kernels even where the LDS-tiled ones apply */
+#define TRANSOAR_MSDA3D_FORK 8u             /* backward: run the coarse-level grad_value walk on an internal side stream */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*

@@ -328,7 +328,7 @@ def test_lds_brick_forward_matches_per_item_kernel(MSDA, vdt):
 @pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
 def test_grad_value_tile_and_cell_walks_vs_c_oracle(MSDA, levels, Lq, vdt):
     """grad_value with C=64 and host shapes: fine levels are accumulated per 4x4x8 brick in an
-    LDS tile, levels with >=128 points per voxel by chunks of sorted points with row atomics.
+    LDS tile, levels with >=32 points per voxel by chunks of sorted points with row atomics.
     Locations reach outside [0,1] so border cells (floor = -1, size-1) are populated."""
     shapes = torch.as_tensor(levels, dtype=torch.long)
     N, M, C, L, P = 2, 3, 64, len(levels), 4
@@ -368,3 +368,20 @@ def test_host_shape_copy_follows_the_tensor_not_its_address(MSDA):
         out = MSDA.ms_deform_attn_forward(v16.cuda(), dev_shapes, lsi.cuda(), loc.cuda(), attn.cuda(), 64)
         assert relerr(out, torch.from_numpy(ref)) <= TOL[torch.bfloat16]
         del dev_shapes
+
+
+def test_forked_grad_value_walk_matches_serial(MSDA):
+    """TRANSOAR_MSDA3D_FORK (flag 8) runs the coarse-level walk on a side stream: same results."""
+    levels = [(9, 6, 11), (5, 3, 6), (2, 2, 3)]
+    value, shapes, lsi, loc, attn = _inputs.model_like_inputs(7, 2, levels, device="cuda")
+    v = value.to(torch.bfloat16)
+    go = torch.randn(2, loc.shape[1], 6 * 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(torch.bfloat16)
+    res = []
+    for fl in (0, 8):
+        MSDA.flags = fl
+        res.append(MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64))
+        torch.cuda.synchronize()
+    MSDA.flags = 0
+    for a, b in zip(*res):
+        assert relerr(a, b) <= TOL[torch.bfloat16]
+

@@ -58,6 +58,31 @@ struct ProfScope {
   }
 };
 
+// Side stream for the coarse-level walk of grad_value: it and the fine-level tile walk are both
+// latency-bound and independent until the final row store, so they are forked onto two streams
+// (event fork / join on the caller's stream; captured as two branches under HIP graph capture).
+// One pair per device, created on first use (an eager call, before any capture).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream* side_stream() {
+  static std::mutex mu;
+  static SideStream per_device[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  SideStream& s = per_device[dev];
+  if (!s.ok && s.stream == nullptr) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
+      s.ok = true;
+  }
+  return s.ok ? &s : nullptr;
+}
+
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
@@ -303,11 +328,11 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
                            rank, recs8, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
       }
-      // levels where a cell holds >= 128 points on average go to the chunked walk
+      // levels whose voxels receive >= kCoarsePointsPerVoxel points each go to the chunked walk
       CoarseLevels cl{d.L, static_cast<int>(cells_per_slab), d.S, 0, 0};
       for (int l = d.L - 1; l >= 0; --l) {
         const long vox = host_shapes[3 * l] * host_shapes[3 * l + 1] * host_shapes[3 * l + 2];
-        if (static_cast<long>(d.Lq) * d.P < 128 * vox) break;
+        if (static_cast<long>(d.Lq) * d.P < kCoarsePointsPerVoxel * vox) break;
         cl.first = l;
         cl.cell_start -= static_cast<int>((host_shapes[3 * l] + 1) * (host_shapes[3 * l + 1] + 1) * (host_shapes[3 * l + 2] + 1));
         cl.row_start = r_order.start[l];
@@ -318,14 +343,25 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       const int fine_bricks = r_order.pad_start[cl.first] >> 7;
       float* scratch = reinterpret_cast<float*>(ws + w.coarse);
       const long scratch_elems = static_cast<long>(d.N) * cl.rows * d.M * kTileC;
+      // opt-in (TRANSOAR_MSDA3D_FORK): 3.90 -> 3.59 ms per eager backward at the flagship, but 1.1 ms per
+      // step SLOWER when the step is replayed as a HIP graph (fork/join nodes), which is how bench.py runs
+      SideStream* side = (g_prof_on || !(flags & TRANSOAR_MSDA3D_FORK) || coarse_levels == 0 || fine_bricks == 0)
+                             ? nullptr : side_stream();
+      hipStream_t cst = st;
+      if (side != nullptr) {
+        TRANSOAR_CHECK_HIP(hipEventRecord(side->fork, st));
+        TRANSOAR_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        cst = side->stream;
+      }
       if (coarse_levels > 0) {
-        ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, st);
-        TRANSOAR_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * scratch_elems, st));
+        ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, cst);
+        TRANSOAR_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * scratch_elems, cst));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
-        hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, st,
+        hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
                            go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl,
                            r_order);
       }
+      if (side != nullptr) TRANSOAR_CHECK_HIP(hipEventRecord(side->join, side->stream));
       ProfScope prof(TRANSOAR_PROF_VALUE_TILE, st);
       if (fine_bricks > 0) {
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
@@ -333,6 +369,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
                            count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
                            d.S, d.M, fine_bricks, n_wg, r_order);
       }
+      if (side != nullptr) TRANSOAR_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
       if (coarse_levels > 0) {
         const long n4 = scratch_elems / 4;
         hipLaunchKernelGGL((msda3d_coarse_rows_store<VT>), dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, st,

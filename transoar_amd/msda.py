@@ -15,6 +15,7 @@ reference dispatches float/double only, .cu:64), kernel launch errors raise
 batch is processed in one launch.
 """
 import ctypes
+import os
 
 import torch
 
@@ -25,7 +26,7 @@ _DT = {torch.float32: _native.F32, torch.float64: _native.F64,
 
 # bit set forwarded to the C ABI (see include/transoar_msda3d.h); module-level so
 # tests can force the generic kernels.
-flags = 0
+flags = int(os.environ.get("TRANSOAR_MSDA_FLAGS", "0"))
 
 
 # host copy of a spatial_shapes tensor, kept ON the tensor object (it dies with it; an address-keyed
