@@ -24,6 +24,8 @@ Host-side differences (same numbers, different schedule):
 """
 import copy
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -168,7 +170,7 @@ class FocusedAttn(nn.Module):
     # so the 27 queries x 8 heads of an organ become 216 rows of ONE plain attention over the organ's raw
     # tokens (dimension C), two batched GEMMs each way, and neither K nor V (B*O*L x C each, plus their
     # data and weight gradient GEMMs over 2*10^5 tokens) is ever formed.  Same arithmetic up to association.
-    fold_projections = True
+    fold_projections = os.environ.get("TRANSOAR_ROI_FOLD", "1") != "0"
 
     def _roi_attention_folded(self, q, k_tok, v_tok, pad, n_org, n_keys):
         b, n_q, c = q.shape

@@ -37,6 +37,7 @@ class TrainStep:
         self.amp_dtype = amp_dtype
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=graph)
         self._graph = None
+        self._expect_total = None
         self._want_graph = graph
         self.num_classes = config["num_classes"]
         self.device_type = next(model.parameters()).device.type
@@ -84,9 +85,12 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._eager_fwd_bwd(self._static_x, self._static_t)
+                eager_total = self._eager_fwd_bwd(self._static_x, self._static_t)[0]
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # the first replay is checked against this eager loss (same inputs and weights; only the
+        # dropout masks differ) before the captured step is trusted: see _replay
+        self._expect_total = float(eager_total)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
@@ -115,6 +119,12 @@ class TrainStep:
             self._static_counts.copy_(self._local_counts(self._static_t))
             self.reducer.reduce_counts(self._static_counts)
         self._graph.replay()
+        if self._expect_total is not None:
+            expect, self._expect_total = self._expect_total, None
+            got = float(self._static_total)
+            if not (got == got and abs(got - expect) <= 0.2 * abs(expect) + 1e-3):
+                self._graph = None
+                raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
         if self.reducer.active:
             for b in self.reducer.buckets:
                 b.handle = torch.distributed.all_reduce(b.flat, op=torch.distributed.ReduceOp.SUM,
