@@ -138,6 +138,12 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    elif os.environ.get("TRANSOAR_FORCE_DP"):
+        # test hook: a ONE-rank RCCL group, so that the whole data-parallel path (communicator, bucketed
+        # all-reduce, rank-summed loss normalisers, graph capture next to the watchdog thread) can be
+        # exercised on a single-GPU box
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from transoar_amd import _native
@@ -273,7 +279,7 @@ def main():
             "loss": round(loss_value, 5), "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
             "roofline": roofline, "msda_kernels": kernels, "cpu_baseline": cpu,
         }))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -92,7 +92,10 @@ class TrainStep:
         # dropout masks differ) before the captured step is trusted: see _replay
         self._expect_total = float(eager_total)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # with a process group alive its watchdog thread polls events while we capture: only calls made
+        # by THIS thread may invalidate the capture
+        mode = "thread_local" if self.reducer.active else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
         self._graph = graph
         return self
