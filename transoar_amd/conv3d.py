@@ -55,7 +55,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Relayout(torch.autograd.Function):
+    """The layout kernels as an autograd node: a change of memory format is the identity on the
+    logical tensor, so the gradient passes through unchanged.  (Calling the raw kernel from a tracked
+    forward returns a tensor without history and silently cuts the graph there.)"""
+
+    @staticmethod
+    def forward(ctx, t, to_channels_first):
+        return _relayout_raw(t, to_channels_first)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 def _relayout(t, to_channels_first):
+    if t.requires_grad and torch.is_grad_enabled():
+        return _Relayout.apply(t, to_channels_first)
+    return _relayout_raw(t, to_channels_first)
+
+
+def _relayout_raw(t, to_channels_first):
     n, c = t.shape[:2]
     v = t.shape[2] * t.shape[3] * t.shape[4]
     out = torch.empty(t.shape, dtype=t.dtype, device=t.device,
