@@ -183,6 +183,7 @@ class _Conv3dK3(torch.autograd.Function):
     # kernels lose to MIOpen's tuned implicit GEMM, which is used through aten otherwise.
     hip_dgrad_strided = False
     hip_wgrad = False
+    miopen_ndhwc = os.environ.get("TRANSOAR_MIOPEN_NDHWC", "1") == "1"
 
     @staticmethod
     def backward(ctx, gy):
@@ -202,8 +203,15 @@ class _Conv3dK3(torch.autograd.Function):
             s = ctx.stride
             # NCDHW-contiguous operands: that is the layout the tuned MIOpen find-db entries
             # (miopen_db/) are keyed on; an NDHWC problem would fall back to MIOpen's naive kernels
+            # miopen_ndhwc: hand MIOpen the channels-last tensors as they are (its CK solvers are NDHWC
+            # natively; given NCDHW it transposes both operands internally on top of our own layout
+            # kernels -- 5 ms per step at stages 0-1).  Needs find-db entries tuned for the NDHWC keys.
+            if _Conv3dK3.miopen_ndhwc and xb.shape[1] > 1:
+                a_gy, a_x = gyb, xb
+            else:
+                a_gy, a_x = to_ncdhw(gyb), to_ncdhw(xb)
             ax, aw, _ = torch.ops.aten.convolution_backward(
-                to_ncdhw(gyb), to_ncdhw(xb), weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                a_gy, a_x, weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
                 [need_x and not hip_x, need_w and not hip_w, False])
             if need_x and not hip_x:
                 gx = ax
