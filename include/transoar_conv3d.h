@@ -70,6 +70,16 @@ int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, in
                                int W, int Cout, void* hip_stream);
 
 /*
+ * Weight gradient of the Cin == 1 first layer (stride 1, pad 1):
+ *   x (N, D, H, W) bf16 ; dy (N, D, H, W, Cout) bf16 ; Cout <= 32 ; W % 16 == 0
+ *   partial (n_partial, 32, 32) fp32, written completely: partial[p][cout][tap] (tap = (kd*3+kh)*3+kw,
+ *   entries with cout >= Cout or tap >= 27 are zero); dW[cout][tap] = sum_p partial[p][cout][tap].
+ * n_partial workgroups share the N*D*H rows of the volume (a few thousand fill the chip).
+ */
+int transoar_conv3d_c1_wgrad(const void* x, const void* dy, float* partial, int n_partial, int N, int D,
+                             int H, int W, int Cout, void* hip_stream);
+
+/*
  * bf16 layout change between channels-last (N, V, C) and channels-first
  * (N, C, V), V = D*H*W, C % 8 == 0.  to_channels_first != 0: in is (N,V,C).
  * Used where a hand-written (NDHWC) layer meets a torch/MIOpen (NCDHW) one.

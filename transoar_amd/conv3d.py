@@ -20,7 +20,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _load():
@@ -32,6 +32,8 @@ def _load():
     lib.transoar_conv3d_k3_forward.argtypes = [p, p, p, p] + [i] * 8 + [p]
     lib.transoar_conv3d_k3_wgrad.restype = i
     lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
+    lib.transoar_conv3d_c1_wgrad.restype = i
+    lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
     lib.transoar_conv3d_c1_forward.argtypes = [p, p, p] + [i] * 5 + [p]
     lib.transoar_layout_bf16.restype = i
@@ -154,6 +156,25 @@ def conv3d_k3_wgrad(x, gy, stride):
     return dw[:, :, :ci].view(3, 3, 3, co, ci).permute(3, 4, 0, 1, 2)
 
 
+C1_WGRAD_PARTIALS = 3200
+
+
+def conv3d_c1_wgrad(x, gy):
+    """x (N,1,D,H,W) bf16 contiguous, gy (N,Cout,D,H,W) bf16 NDHWC -> dW (Cout,1,3,3,3) fp32."""
+    n, _, d, h, w = x.shape
+    co = gy.shape[1]
+    n_part = min(C1_WGRAD_PARTIALS, max(1, (n * d * h + 3) // 4))
+    partial = torch.empty((n_part, 32, 32), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_c1_wgrad(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), n_part, n, d, h, w, co,
+                                            _stream()), "transoar_conv3d_c1_wgrad")
+    return partial.sum(0)[:co, :27].reshape(co, 1, 3, 3, 3)
+
+
+def c1_wgrad_supported(x, gy):
+    return x.shape[1] == 1 and gy.shape[1] <= 32 and x.shape[-1] % 16 == 0 and x.is_contiguous()
+
+
 class _Conv3dK3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
@@ -197,7 +218,9 @@ class _Conv3dK3(torch.autograd.Function):
             # data gradient = convolution of dy with the flipped, in/out-swapped filter
             wt = weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, weight.shape[1], weight.shape[0])
             gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
-        if hip_w:
+        if need_w and ctx.stride == 1 and c1_wgrad_supported(xb, gyb):
+            gw, hip_w = conv3d_c1_wgrad(xb, gyb).to(weight.dtype), True       # one input channel: MFMA over voxel chunks
+        elif hip_w:
             gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
         if (need_x and not hip_x) or (need_w and not hip_w):
             s = ctx.stride

@@ -378,6 +378,80 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __res
 }
 
 // ---------------------------------------------------------------------------
+// Cin == 1 weight gradient:  dW[cout][tap] = sum_voxels dy[voxel][cout] * x[voxel + tap]
+//   x (N,D,H,W) bf16 ; dy (N,D,H,W,Cout) bf16 (NDHWC) ; Cout <= 32 ; W % 16 == 0
+//   partial (gridDim.x, 32, 32) fp32: per workgroup the 32x32 (cout x tap) tile, rows >= Cout and
+//   columns >= 27 zero; the caller sums over workgroups.
+// One v_mfma_f32_32x32x16_bf16 per 16 consecutive voxels of a W-row: A = dy^T (cout x voxel),
+// B = the 27 shifted views of x (voxel x tap).  Both operands are gathered with 2-byte loads (8 per
+// lane each; the voxel axis is the slow one in memory) -- the kernel is bound by that, not by the
+// MFMA: 630 MB of dy once, x from L2.  (aten's fallback for this layer is im2col + a 16x16-tile
+// GEMM per sample: 3.9 ms; this: see profiles/.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ dy,
+                                                       float* __restrict__ partial, int N, int D, int H, int W,
+                                                       int Cout, long n_rows, int rows_per_wave) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  // B side: this lane's tap
+  const int tap = col;
+  const bool tap_ok = tap < 27;
+  const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+  // A side: this lane's output channel
+  const bool co_ok = col < Cout;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const long row0 = (static_cast<long>(blockIdx.x) * 4 + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const long row = row0 + rr;                        // (b*D + d)*H + h
+    if (row >= n_rows) break;
+    const int h = static_cast<int>(row % H);
+    const long bd = row / H;
+    const int d = static_cast<int>(bd % D);
+    const int id = d + kd, ih = h + kh;
+    const bool row_ok = tap_ok && static_cast<unsigned>(id) < static_cast<unsigned>(D) &&
+                        static_cast<unsigned>(ih) < static_cast<unsigned>(H);
+    const unsigned short* xrow = x + ((bd - d + (row_ok ? id : d)) * H + (row_ok ? ih : h)) * W;   // clamped: always valid
+    const unsigned short* dyrow = dy + row * W * Cout + (co_ok ? col : 0);
+    for (int w0 = 0; w0 < W; w0 += 16) {
+      unsigned short av[8], bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w = w0 + 8 * kg + j;
+        av[j] = dyrow[static_cast<long>(w) * Cout];
+        const int iw = w + kw;
+        const unsigned short xv = xrow[min(max(iw, 0), W - 1)];
+        bv[j] = (row_ok && static_cast<unsigned>(iw) < static_cast<unsigned>(W)) ? xv : static_cast<unsigned short>(0);
+      }
+      u32x4c ap, bp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ap[j] = co_ok ? (static_cast<unsigned>(av[2 * j]) | (static_cast<unsigned>(av[2 * j + 1]) << 16)) : 0u;
+        bp[j] = static_cast<unsigned>(bv[2 * j]) | (static_cast<unsigned>(bv[2 * j + 1]) << 16);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bp), acc,
+                                                    0, 0, 0);
+    }
+  }
+  // 4 waves -> one tile: D[row = (r&3) + 8*(r>>2) + 4*kg][col]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + static_cast<long>(blockIdx.x) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+      out[((r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + col] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // layout changes between channels-last (N, V, C) and channels-first (N, C, V),
 // bf16.  One thread per voxel: 16-byte accesses on the channels-last side
 // (8 channels of its voxel), 2-byte accesses coalesced across the wave on the
@@ -491,6 +565,19 @@ extern "C" int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float*
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_conv3d_c1_wgrad(const void* x, const void* dy, float* partial, int n_partial, int N, int D, int H,
+                                        int W, int Cout, void* hip_stream) {
+  if (!x || !dy || !partial) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || n_partial <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (Cout > 32 || (W & 15)) return TRANSOAR_CONV_ERR_CHANNELS;
+  const long n_rows = static_cast<long>(N) * D * H;
+  const int rows_per_wave = static_cast<int>((n_rows + static_cast<long>(n_partial) * 4 - 1) / (static_cast<long>(n_partial) * 4));
+  hipLaunchKernelGGL(conv3d_c1_wgrad, dim3(static_cast<unsigned>(n_partial)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(x),
+                     static_cast<const unsigned short*>(dy), partial, N, D, H, W, Cout, n_rows, rows_per_wave);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H, int W,
                                           int Cout, void* hip_stream) {
   if (!x || !w || !y) return TRANSOAR_CONV_ERR_NULL;
@@ -519,4 +606,4 @@ extern "C" int transoar_layout_bf16(const void* in, void* out, int N, long V, in
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_conv3d_abi_version(void) { return 2; }
+extern "C" int transoar_conv3d_abi_version(void) { return 3; }
