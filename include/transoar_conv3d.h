@@ -70,6 +70,16 @@ int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, in
                                int W, int Cout, void* hip_stream);
 
 /*
+ * Weight gradient, stride 1 / pad 1, few channels: Cin, Cout multiples of 8 and <= 32, W % 64 == 0.
+ *   x (N, D, H, W, Cin) bf16 ; dy (N, D, H, W, Cout) bf16 (both NDHWC)
+ *   partial (n_wg, 27, 32, 32) fp32, written completely: partial[g][tap][cout][cin];
+ *   dW[cout][cin][tap] = sum_g partial[g][tap][cout][cin]   (tap = (kd*3+kh)*3+kw).
+ * n_wg workgroups (a few per CU) share the N*D*H*(W/64) row segments.
+ */
+int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, int n_wg, int N, int D,
+                                 int H, int W, int Cin, int Cout, void* hip_stream);
+
+/*
  * Weight gradient of the Cin == 1 first layer (stride 1, pad 1):
  *   x (N, D, H, W) bf16 ; dy (N, D, H, W, Cout) bf16 ; Cout <= 32 ; W % 16 == 0
  *   partial (n_partial, 32, 32) fp32, written completely: partial[p][cout][tap] (tap = (kd*3+kh)*3+kw,

@@ -32,6 +32,8 @@ def _load():
     lib.transoar_conv3d_k3_forward.argtypes = [p, p, p, p] + [i] * 8 + [p]
     lib.transoar_conv3d_k3_wgrad.restype = i
     lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
+    lib.transoar_conv3d_k3_wgrad_lds.restype = i
+    lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 6 + [p]
     lib.transoar_conv3d_c1_wgrad.restype = i
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
@@ -171,6 +173,27 @@ def conv3d_c1_wgrad(x, gy):
     return partial.sum(0)[:co, :27].reshape(co, 1, 3, 3, 3)
 
 
+LDS_WGRAD_GROUPS = 512
+
+
+def conv3d_k3_wgrad_lds(x, gy):
+    """x (N,Cin,D,H,W), gy (N,Cout,D,H,W) bf16 NDHWC, stride 1 -> dW (Cout,Cin,3,3,3) fp32
+    (LDS-transposed MFMA kernel for Cin, Cout <= 32, W % 64 == 0)."""
+    n, ci, d, h, w = x.shape
+    co = gy.shape[1]
+    partial = torch.empty((LDS_WGRAD_GROUPS, 27, 32, 32), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_k3_wgrad_lds(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), LDS_WGRAD_GROUPS,
+                                                n, d, h, w, ci, co, _stream()), "transoar_conv3d_k3_wgrad_lds")
+    return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3, 3)
+
+
+def lds_wgrad_supported(x, gy):
+    ci, co = x.shape[1], gy.shape[1]
+    return (ci % 8 == 0 and co % 8 == 0 and ci <= 32 and co <= 32 and x.shape[-1] % 64 == 0
+            and x.is_contiguous(memory_format=CL3D) and gy.is_contiguous(memory_format=CL3D))
+
+
 def c1_wgrad_supported(x, gy):
     return x.shape[1] == 1 and gy.shape[1] <= 32 and x.shape[-1] % 16 == 0 and x.is_contiguous()
 
@@ -220,6 +243,8 @@ class _Conv3dK3(torch.autograd.Function):
             gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
         if need_w and ctx.stride == 1 and c1_wgrad_supported(xb, gyb):
             gw, hip_w = conv3d_c1_wgrad(xb, gyb).to(weight.dtype), True       # one input channel: MFMA over voxel chunks
+        elif need_w and ctx.stride == 1 and lds_wgrad_supported(xb, gyb):
+            gw, hip_w = conv3d_k3_wgrad_lds(xb, gyb).to(weight.dtype), True   # few channels, 10^7 voxels: LDS-transposed MFMA
         elif hip_w:
             gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
         if (need_x and not hip_x) or (need_w and not hip_w):

@@ -451,6 +451,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const unsigned short* __r
   }
 }
 
+#include "conv3d_wgrad_lds.hpp"
+
 // ---------------------------------------------------------------------------
 // layout changes between channels-last (N, V, C) and channels-first (N, C, V),
 // bf16.  One thread per voxel: 16-byte accesses on the channels-last side
@@ -563,6 +565,30 @@ extern "C" int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float*
                      static_cast<const unsigned short*>(xT3), dw, g, rows_per_block,
                      static_cast<unsigned>(gy_bytes), static_cast<unsigned>(x_bytes));
   return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, int n_wg, int N, int D, int H,
+                                            int W, int Cin, int Cout, void* hip_stream) {
+  if (!x || !dy || !partial) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_wg <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (Cin <= 0 || Cout <= 0 || Cin > 32 || Cout > 32 || (Cin & 7) || (Cout & 7) || (W & 63)) return TRANSOAR_CONV_ERR_CHANNELS;
+  const long n_units = static_cast<long>(N) * D * H * (W / 64);
+  const int per = static_cast<int>((n_units + n_wg - 1) / n_wg);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  auto xs = static_cast<const unsigned short*>(x);
+  auto ds = static_cast<const unsigned short*>(dy);
+#define TRANSOAR_WG_CASE(CI, CO)                                                                         \
+  if (Cin == 8 * CI && Cout == 8 * CO) {                                                                 \
+    hipLaunchKernelGGL((conv3d_k3_wgrad_lds<CI, CO>), dim3(static_cast<unsigned>(n_wg)), dim3(kWgThreads), 0, st, xs, ds, \
+                       partial, N, D, H, W, n_units, per);                                               \
+    return static_cast<int>(hipGetLastError());                                                          \
+  }
+  TRANSOAR_WG_CASE(1, 1) TRANSOAR_WG_CASE(1, 2) TRANSOAR_WG_CASE(1, 3) TRANSOAR_WG_CASE(1, 4)
+  TRANSOAR_WG_CASE(2, 1) TRANSOAR_WG_CASE(2, 2) TRANSOAR_WG_CASE(2, 3) TRANSOAR_WG_CASE(2, 4)
+  TRANSOAR_WG_CASE(3, 1) TRANSOAR_WG_CASE(3, 2) TRANSOAR_WG_CASE(3, 3) TRANSOAR_WG_CASE(3, 4)
+  TRANSOAR_WG_CASE(4, 1) TRANSOAR_WG_CASE(4, 2) TRANSOAR_WG_CASE(4, 3) TRANSOAR_WG_CASE(4, 4)
+#undef TRANSOAR_WG_CASE
+  return TRANSOAR_CONV_ERR_CHANNELS;
 }
 
 extern "C" int transoar_conv3d_c1_wgrad(const void* x, const void* dy, float* partial, int n_partial, int N, int D, int H,

@@ -1,0 +1,152 @@
+// Weight gradient of a 3x3x3 / stride 1 / pad 1 convolution with few channels (Cin, Cout <= 32),
+// the contraction running over 10^7 voxels:   dW[cout][cin][tap] = sum_v dy[v][cout] * x[v + tap][cin]
+// with x, dy NDHWC bf16.  MFMA wants 8 consecutive contraction elements (voxels) per lane, memory has
+// the channels contiguous instead -> both operands are transposed on their way into LDS:
+//   unit of work   64 consecutive voxels of a W-row (b, d, h, w0..w0+63)
+//   GT[cout][64]                      dy tile, voxel-contiguous
+//   XT[9 rows (kd,kh)][cin][66(+pad)] the 9 neighbouring rows of x, w0-1 .. w0+64, zero outside the volume
+//   3 waves, wave kd owns the 9 taps (kd, kh, kw): per 16-voxel k-step one A fragment (ds_read_b128 of
+//   GT) and per (kd,kh) row two aligned ds_read_b128 of XT from which the three kw-shifted B fragments
+//   are cut with v_alignbit; 9 x v_mfma_f32_32x32x16_bf16.  Accumulators (9 x 32x32 fp32 per wave) live
+//   in registers across all units of the workgroup; the caller sums the per-workgroup partials.
+// Included by conv3d.hip (inside namespace transoar).
+#pragma once
+
+constexpr int kWgGPitch = 72;                  // elements per GT row (64 + pad against bank conflicts)
+constexpr int kWgXPitch = 88;                  // elements per XT row: 66 used, 16-byte aligned windows up to 80
+constexpr int kWgThreads = 192;
+
+__device__ __forceinline__ unsigned int wg_alignbit(unsigned int hi, unsigned int lo, int bits) {
+  return bits == 0 ? lo : static_cast<unsigned int>(((static_cast<unsigned long long>(hi) << 32) | lo) >> bits);
+}
+
+template <int CIN8, int COUT8>
+__global__ __launch_bounds__(kWgThreads) void conv3d_k3_wgrad_lds(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ partial,
+    int N, int D, int H, int W, long n_units, int units_per_wg) {
+  constexpr int Cin = CIN8 * 8, Cout = COUT8 * 8;
+  constexpr int kGItems = (64 * COUT8 + kWgThreads - 1) / kWgThreads;
+  constexpr int kXItems = (9 * 66 * CIN8 + kWgThreads - 1) / kWgThreads;
+  __shared__ __attribute__((aligned(16))) unsigned short GT[32 * kWgGPitch];
+  __shared__ __attribute__((aligned(16))) unsigned short XT[9 * 32 * kWgXPitch];
+  const int tid = threadIdx.x, lane = tid & 63, kd = tid >> 6;       // wave = kd
+  const int col = lane & 31, kg = lane >> 5;
+  const int segs = W / 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // rows of GT / XT beyond Cout / Cin stay zero for the whole kernel
+  for (int i = tid; i < 32 * kWgGPitch / 2; i += kWgThreads) reinterpret_cast<unsigned int*>(GT)[i] = 0u;
+  for (int i = tid; i < 9 * 32 * kWgXPitch / 2; i += kWgThreads) reinterpret_cast<unsigned int*>(XT)[i] = 0u;
+
+  // all 16-byte loads of a thread for one unit (dy: 64 voxels x Cout; x: 9 rows x 66 voxels x Cin, zero
+  // outside the volume); lanes = consecutive voxels -> consecutive LDS columns when transposed below
+  u32x4c graw[kGItems], xraw[kXItems];
+  auto fetch = [&](long u) {
+    const int seg = static_cast<int>(u % segs);
+    const long row = u / segs;                                   // (b*D + d)*H + h
+    const int h = static_cast<int>(row % H);
+    const long bd = row / H;
+    const int d = static_cast<int>(bd % D);
+    const int w0 = seg * 64;
+#pragma unroll
+    for (int k = 0; k < kGItems; ++k) {
+      const int i = tid + k * kWgThreads;
+      graw[k] = u32x4c{0u, 0u, 0u, 0u};
+      if (i < 64 * COUT8) {
+        const int c8 = i / 64, v = i - c8 * 64;
+        graw[k] = *reinterpret_cast<const u32x4c*>(dy + (row * W + w0 + v) * Cout + c8 * 8);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kXItems; ++k) {
+      const int i = tid + k * kWgThreads;
+      xraw[k] = u32x4c{0u, 0u, 0u, 0u};
+      if (i < 9 * 66 * CIN8) {
+        const int vw = i % 66;
+        const int t = i / 66;
+        const int c8 = t % CIN8, r = t / CIN8;
+        const int id = d + r / 3 - 1, ih = h + r % 3 - 1, iw = w0 + vw - 1;
+        if (static_cast<unsigned>(id) < static_cast<unsigned>(D) && static_cast<unsigned>(ih) < static_cast<unsigned>(H) &&
+            static_cast<unsigned>(iw) < static_cast<unsigned>(W))
+          xraw[k] = *reinterpret_cast<const u32x4c*>(x + (((bd - d + id) * H + ih) * W + iw) * Cin + c8 * 8);
+      }
+    }
+  };
+
+  const long u0 = static_cast<long>(blockIdx.x) * units_per_wg;
+  const long u_end = min(u0 + units_per_wg, n_units);
+  if (u0 < u_end) fetch(u0);
+  __syncthreads();
+  for (long u = u0; u < u_end; ++u) {
+    // ---- registers -> LDS, transposed (2-byte writes)
+#pragma unroll
+    for (int k = 0; k < kGItems; ++k) {
+      const int i = tid + k * kWgThreads;
+      if (i < 64 * COUT8) {
+        const int c8 = i / 64, v = i - c8 * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          GT[(c8 * 8 + 2 * e) * kWgGPitch + v] = static_cast<unsigned short>(graw[k][e] & 0xffffu);
+          GT[(c8 * 8 + 2 * e + 1) * kWgGPitch + v] = static_cast<unsigned short>(graw[k][e] >> 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kXItems; ++k) {
+      const int i = tid + k * kWgThreads;
+      if (i < 9 * 66 * CIN8) {
+        const int vw = i % 66;
+        const int t = i / 66;
+        const int c8 = t % CIN8, r = t / CIN8;
+        unsigned short* dst = XT + (r * 32 + c8 * 8) * kWgXPitch + vw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[(2 * e) * kWgXPitch] = static_cast<unsigned short>(xraw[k][e] & 0xffffu);
+          dst[(2 * e + 1) * kWgXPitch] = static_cast<unsigned short>(xraw[k][e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (u + 1 < u_end) fetch(u + 1);          // in flight during the MFMA phase
+
+    // ---- 4 k-steps of 16 voxels; this wave: taps (kd, kh, kw)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int v0 = ks * 16 + 8 * kg;                            // first voxel of this lane's 8
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(GT + col * kWgGPitch + v0);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        // XT column index of voxel v, tap kw:  v + kw  (column 0 is w0-1)
+        const unsigned short* src = XT + ((kd * 3 + kh) * 32 + col) * kWgXPitch + v0;
+        const u32x4c lo = *reinterpret_cast<const u32x4c*>(src);
+        const u32x4c hi = *reinterpret_cast<const u32x4c*>(src + 8);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          u32x4c b;
+          if (kw == 0) {
+            b = lo;
+          } else if (kw == 1) {
+            b[0] = wg_alignbit(lo[1], lo[0], 16); b[1] = wg_alignbit(lo[2], lo[1], 16);
+            b[2] = wg_alignbit(lo[3], lo[2], 16); b[3] = wg_alignbit(hi[0], lo[3], 16);
+          } else {      // shift by 32 bits: whole dwords
+            b[0] = lo[1]; b[1] = lo[2]; b[2] = lo[3]; b[3] = hi[0];
+          }
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // partial[wg][tap = (kd*3+kh)*3+kw][cout][cin]
+  float* out = partial + (static_cast<long>(blockIdx.x) * 27 + kd * 9) * 1024;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + col] = acc[t][r];
+}
