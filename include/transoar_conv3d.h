@@ -70,14 +70,17 @@ int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, in
                                int W, int Cout, void* hip_stream);
 
 /*
- * Weight gradient, stride 1 / pad 1, few channels: Cin, Cout multiples of 8 and <= 32, W % 64 == 0.
- *   x (N, D, H, W, Cin) bf16 ; dy (N, D, H, W, Cout) bf16 (both NDHWC)
- *   partial (n_wg, 27, 32, 32) fp32, written completely: partial[g][tap][cout][cin];
- *   dW[cout][cin][tap] = sum_g partial[g][tap][cout][cin]   (tap = (kd*3+kh)*3+kw).
- * n_wg workgroups (a few per CU) share the N*D*H*(W/64) row segments.
+ * Weight gradient, stride 1 / pad 1, of one block of at most 32 x 32 channels; W % 64 == 0.
+ *   x (N, D, H, W, Cin) bf16 ; dy (N, D, H, W, Cout) bf16 (both NDHWC), Cin and Cout multiples of 8
+ *   block = input channels [ci0, ci0 + ci_n), output channels [co0, co0 + co_n); ci_n, co_n multiples
+ *   of 8 and <= 32 (a 48 -> 48 layer takes 4 calls)
+ *   partial (n_wg, 27, 32, 32) fp32, written completely: partial[g][tap][cout - co0][cin - ci0];
+ *   dW[cout][cin][tap] = sum_g partial[g][tap][cout - co0][cin - ci0]   (tap = (kd*3+kh)*3+kw).
+ * n_wg workgroups (two per CU) share the N*D*H*(W/64) row segments.
  */
 int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, int n_wg, int N, int D,
-                                 int H, int W, int Cin, int Cout, void* hip_stream);
+                                 int H, int W, int Cin, int Cout, int ci0, int ci_n, int co0, int co_n,
+                                 void* hip_stream);
 
 /*
  * Weight gradient of the Cin == 1 first layer (stride 1, pad 1):

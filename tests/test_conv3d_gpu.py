@@ -19,6 +19,7 @@ CASES = [  # N, Cin, Cout, D, H, W, stride, bias
     (1, 96, 96, 5, 5, 8, 1, False), (1, 96, 384, 4, 4, 8, 1, True), (2, 8, 40, 3, 7, 24, 1, True),
     (1, 1, 24, 6, 10, 16, 1, False), (1, 192, 64, 2, 2, 8, 1, True),
     (2, 24, 24, 3, 4, 64, 1, False), (1, 8, 32, 2, 3, 128, 1, False), (1, 32, 16, 3, 2, 64, 1, False),   # LDS-transposed wgrad
+    (1, 48, 48, 3, 3, 64, 1, False), (1, 40, 64, 2, 2, 64, 1, True),    # ... in 32-channel blocks
     (2, 1, 32, 3, 4, 32, 1, False), (1, 1, 8, 2, 3, 48, 1, False), (3, 1, 24, 5, 3, 16, 1, False),   # Cin=1: MFMA weight gradient
 ]
 

@@ -34,7 +34,7 @@ int main() {
     unsigned short *x, *dy; float* part;
     hipMalloc(&x, hx.size() * 2); hipMalloc(&dy, hdy.size() * 2); hipMalloc(&part, (size_t)n_wg * 27 * 1024 * 4);
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dy, hdy.data(), hdy.size() * 2, hipMemcpyHostToDevice);
-    int rc = transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, nullptr);
+    int rc = transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, 0, Cin, 0, Cout, nullptr);
     hipDeviceSynchronize();
     std::vector<float> hp((size_t)n_wg * 27 * 1024);
     hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost);
@@ -56,9 +56,9 @@ int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int n_wg : {256, 512, 768, 1024, 1536}) {
       hipMalloc(&part, (size_t)n_wg * 27 * 1024 * 4);
-      for (int i = 0; i < 2; ++i) transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, nullptr);
+      for (int i = 0; i < 2; ++i) transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, 0, Cin, 0, Cout, nullptr);
       hipEventRecord(a);
-      for (int i = 0; i < 5; ++i) transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, nullptr);
+      for (int i = 0; i < 5; ++i) transoar_conv3d_k3_wgrad_lds(x, dy, part, n_wg, N, D, H, W, Cin, Cout, 0, Cin, 0, Cout, nullptr);
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       printf("n_wg %4d: %.3f ms  (%s)\n", n_wg, ms / 5, hipGetErrorString(hipGetLastError()));

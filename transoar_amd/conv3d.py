@@ -20,7 +20,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _load():
@@ -33,7 +33,7 @@ def _load():
     lib.transoar_conv3d_k3_wgrad.restype = i
     lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
     lib.transoar_conv3d_k3_wgrad_lds.restype = i
-    lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 6 + [p]
+    lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 10 + [p]
     lib.transoar_conv3d_c1_wgrad.restype = i
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
@@ -178,19 +178,25 @@ LDS_WGRAD_GROUPS = 512
 
 def conv3d_k3_wgrad_lds(x, gy):
     """x (N,Cin,D,H,W), gy (N,Cout,D,H,W) bf16 NDHWC, stride 1 -> dW (Cout,Cin,3,3,3) fp32
-    (LDS-transposed MFMA kernel for Cin, Cout <= 32, W % 64 == 0)."""
+    (LDS-transposed MFMA kernel, one launch per block of <= 32 x 32 channels, W % 64 == 0)."""
     n, ci, d, h, w = x.shape
     co = gy.shape[1]
-    partial = torch.empty((LDS_WGRAD_GROUPS, 27, 32, 32), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _check(lib.transoar_conv3d_k3_wgrad_lds(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), LDS_WGRAD_GROUPS,
-                                                n, d, h, w, ci, co, _stream()), "transoar_conv3d_k3_wgrad_lds")
-    return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3, 3)
+    dw = torch.empty((co, ci, 27), dtype=torch.float32, device=x.device)
+    for co0 in range(0, co, 32):
+        for ci0 in range(0, ci, 32):
+            co_n, ci_n = min(32, co - co0), min(32, ci - ci0)
+            partial = torch.empty((LDS_WGRAD_GROUPS, 27, 32, 32), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _check(lib.transoar_conv3d_k3_wgrad_lds(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), LDS_WGRAD_GROUPS,
+                                                        n, d, h, w, ci, co, ci0, ci_n, co0, co_n, _stream()),
+                       "transoar_conv3d_k3_wgrad_lds")
+            dw[co0:co0 + co_n, ci0:ci0 + ci_n] = partial.sum(0)[:, :co_n, :ci_n].permute(1, 2, 0)
+    return dw.view(co, ci, 3, 3, 3)
 
 
 def lds_wgrad_supported(x, gy):
     ci, co = x.shape[1], gy.shape[1]
-    return (ci % 8 == 0 and co % 8 == 0 and ci <= 32 and co <= 32 and x.shape[-1] % 64 == 0
+    return (ci % 8 == 0 and co % 8 == 0 and ci <= 64 and co <= 64 and x.shape[-1] % 64 == 0
             and x.is_contiguous(memory_format=CL3D) and gy.is_contiguous(memory_format=CL3D))
 
 

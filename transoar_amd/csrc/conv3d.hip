@@ -568,19 +568,23 @@ extern "C" int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float*
 }
 
 extern "C" int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, int n_wg, int N, int D, int H,
-                                            int W, int Cin, int Cout, void* hip_stream) {
+                                            int W, int Cin, int Cout, int ci0, int ci_n, int co0, int co_n,
+                                            void* hip_stream) {
   if (!x || !dy || !partial) return TRANSOAR_CONV_ERR_NULL;
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_wg <= 0) return TRANSOAR_CONV_ERR_DIM;
-  if (Cin <= 0 || Cout <= 0 || Cin > 32 || Cout > 32 || (Cin & 7) || (Cout & 7) || (W & 63)) return TRANSOAR_CONV_ERR_CHANNELS;
+  if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 7) || (W & 63)) return TRANSOAR_CONV_ERR_CHANNELS;
+  if (ci_n <= 0 || co_n <= 0 || ci_n > 32 || co_n > 32 || (ci_n & 7) || (co_n & 7) || (ci0 & 7) || (co0 & 7) ||
+      ci0 < 0 || co0 < 0 || ci0 + ci_n > Cin || co0 + co_n > Cout)
+    return TRANSOAR_CONV_ERR_CHANNELS;
   const long n_units = static_cast<long>(N) * D * H * (W / 64);
   const int per = static_cast<int>((n_units + n_wg - 1) / n_wg);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   auto xs = static_cast<const unsigned short*>(x);
   auto ds = static_cast<const unsigned short*>(dy);
 #define TRANSOAR_WG_CASE(CI, CO)                                                                         \
-  if (Cin == 8 * CI && Cout == 8 * CO) {                                                                 \
+  if (ci_n == 8 * CI && co_n == 8 * CO) {                                                                \
     hipLaunchKernelGGL((conv3d_k3_wgrad_lds<CI, CO>), dim3(static_cast<unsigned>(n_wg)), dim3(kWgThreads), 0, st, xs, ds, \
-                       partial, N, D, H, W, n_units, per);                                               \
+                       partial, N, D, H, W, n_units, per, Cin, ci0, Cout, co0);                          \
     return static_cast<int>(hipGetLastError());                                                          \
   }
   TRANSOAR_WG_CASE(1, 1) TRANSOAR_WG_CASE(1, 2) TRANSOAR_WG_CASE(1, 3) TRANSOAR_WG_CASE(1, 4)
@@ -632,4 +636,4 @@ extern "C" int transoar_layout_bf16(const void* in, void* out, int N, long V, in
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_conv3d_abi_version(void) { return 3; }
+extern "C" int transoar_conv3d_abi_version(void) { return 4; }

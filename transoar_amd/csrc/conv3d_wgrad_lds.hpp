@@ -24,8 +24,8 @@ __device__ __forceinline__ unsigned int wg_alignbit(unsigned int hi, unsigned in
 template <int CIN8, int COUT8>
 __global__ __launch_bounds__(kWgThreads) void conv3d_k3_wgrad_lds(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ partial,
-    int N, int D, int H, int W, long n_units, int units_per_wg) {
-  constexpr int Cin = CIN8 * 8, Cout = COUT8 * 8;
+    int N, int D, int H, int W, long n_units, int units_per_wg, int cin_total, int ci0, int cout_total, int co0) {
+  // this launch: channels [ci0, ci0 + 8*CIN8) of x rows that are cin_total wide, same for dy
   constexpr int kGItems = (64 * COUT8 + kWgThreads - 1) / kWgThreads;
   constexpr int kXItems = (3 * 66 * CIN8 + kWgThreads - 1) / kWgThreads;      // one new h-row per kd
   __shared__ __attribute__((aligned(16))) unsigned short GT[32 * kWgGPitch];
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kWgThreads) void conv3d_k3_wgrad_lds(
     u32x4c v = {0u, 0u, 0u, 0u};
     if (static_cast<unsigned>(id) < static_cast<unsigned>(D) && static_cast<unsigned>(ih) < static_cast<unsigned>(H) &&
         static_cast<unsigned>(iw) < static_cast<unsigned>(W))
-      v = *reinterpret_cast<const u32x4c*>(x + (((bd - d + id) * H + ih) * W + iw) * Cin + c8 * 8);
+      v = *reinterpret_cast<const u32x4c*>(x + (((bd - d + id) * H + ih) * W + iw) * cin_total + ci0 + c8 * 8);
     return v;
   };
   auto x_store = [&](int kdd, int ih, int vw, int c8, const u32x4c& v) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWgThreads) void conv3d_k3_wgrad_lds(
       graw[k] = u32x4c{0u, 0u, 0u, 0u};
       if (i < 64 * COUT8) {
         const int c8 = i / 64, v = i - c8 * 64;
-        graw[k] = *reinterpret_cast<const u32x4c*>(dy + ((bd * H + h) * W + w0 + v) * Cout + c8 * 8);
+        graw[k] = *reinterpret_cast<const u32x4c*>(dy + ((bd * H + h) * W + w0 + v) * cout_total + co0 + c8 * 8);
       }
     }
     if (h > 0) {
