@@ -211,10 +211,12 @@ __global__ __launch_bounds__(kINThreads) void instnorm_bwd_dx(
   }
 }
 
-static int pick_blocks(long V, int N) {
-  // ~4 blocks per CU overall, at least 4096 voxels per block
+static int pick_blocks(long V, int N, int C) {
+  // ~4 blocks per CU overall; a thread should still have >= 8 of the 16-byte pieces (V * C/8 per sample)
+  // to walk -- the deep encoder stages have a few hundred voxels per sample, and one block per sample
+  // (the old "at least 4096 voxels per block") left them to 2 workgroups: 0.1-0.3 ms per call
   long per = (4L * 256 + N - 1) / N;
-  const long cap = (V + 4095) / 4096;
+  const long cap = (V * (C >> 3) + 8L * kINThreads - 1) / (8L * kINThreads);
   if (per > cap) per = cap;
   return static_cast<int>(per < 1 ? 1 : per);
 }
@@ -237,7 +239,7 @@ extern "C" int transoar_instnorm_relu_forward(const void* x, const float* gamma,
   if (rc) return rc;
   if (!gamma || !beta || !stats_ws || !mean_rstd) return TRANSOAR_IN_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const int bps = pick_blocks(V, N);
+  const int bps = pick_blocks(V, N, C);
   hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * N * C, st);
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL(instnorm_stats, dim3(N * bps), dim3(kINThreads), 0, st, static_cast<const unsigned short*>(x),
@@ -255,7 +257,7 @@ extern "C" int transoar_instnorm_relu_backward(const void* x, const void* dy, co
   if (rc) return rc;
   if (!gamma || !beta || !mean_rstd || !dx || !red_ws) return TRANSOAR_IN_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const int bps = pick_blocks(V, N);
+  const int bps = pick_blocks(V, N, C);
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(double) * 2 * N * C, st);
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL(instnorm_bwd_reduce, dim3(N * bps), dim3(kINThreads), 0, st,
