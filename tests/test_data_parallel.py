@@ -46,7 +46,9 @@ def _worker(rank, world, port, ref_path, out_path):
     tg = _targets(2)[rank:rank + 1]
     ref = torch.load(ref_path)
     errs = []
-    for it in range(2):                    # second pass exercises the "dead params known" path
+    # a second pass exercises the "dead params known" path of the reducer; it doubles the run time of the
+    # slowest CPU test (fp64 on the full 160x160x256 volume), so it is opt-in
+    for it in range(2 if os.environ.get("TRANSOAR_SLOW_TESTS") else 1):
         step.reducer.begin()
         total, _ = step.loss(x, tg)
         total.backward()
