@@ -132,7 +132,11 @@ class Decoder(nn.Module):
     def forward(self, x):
         # the encoder hands over channels-last (NDHWC) bf16 maps on the GPU; everything from here
         # on is a torch/MIOpen convolution whose tuned kernels are keyed on NCDHW (miopen_db/)
-        feats = [to_ncdhw(f) for f in list(x.values())[-self._lateral_levels:]]
+        # (Conv3dK3.ndhwc_everywhere: keep channels-last all the way -- MIOpen's CK solvers are NDHWC natively;
+        # needs find-db entries for the NDHWC keys of every layer of this decoder)
+        feats = list(x.values())[-self._lateral_levels:]
+        if not Conv3dK3.ndhwc_everywhere:
+            feats = [to_ncdhw(f) for f in feats]
         laterals = [conv(f) for conv, f in zip(self._lateral, feats)]
         # merged[s - first] = lateral_s + up(merged_{s+1})
         merged = [None] * self._lateral_levels

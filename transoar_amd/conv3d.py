@@ -292,6 +292,7 @@ class Conv3dK3(nn.Conv3d):
     v1 kernel (no split-K) and the layer stays on MIOpen."""
     enabled = True
     min_voxels = 1 << 20
+    ndhwc_everywhere = os.environ.get("TRANSOAR_NDHWC_ALL", "0") == "1"
 
     def forward(self, x):
         amp = torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_gpu_dtype() == torch.bfloat16
@@ -302,4 +303,6 @@ class Conv3dK3(nn.Conv3d):
             if voxels >= Conv3dK3.min_voxels:
                 return _Conv3dK3.apply(xb, self.weight, self.bias, s)
         # stock convolution (MIOpen on the GPU): NCDHW-contiguous input, see the note in backward
-        return super().forward(to_ncdhw(x) if x.is_cuda else x)
+        if x.is_cuda and not Conv3dK3.ndhwc_everywhere:
+            x = to_ncdhw(x)
+        return super().forward(x)
