@@ -24,6 +24,8 @@
 // (rows = cout) so that a lane ends up with 4 consecutive output channels of
 // one voxel per accumulator quad -> 8-byte stores into the NDHWC output.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "../../include/transoar_conv3d.h"
