@@ -157,10 +157,6 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
-    # refine off: the captured step of that model variant is not reproducible on ROCm 7.2 (NaN loss on
-    # replay or a host fault in hipGraphInstantiate) -> that variant is timed eagerly
-    if args.no_refine:
-        args.no_graph = True
     step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
