@@ -132,10 +132,13 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_fwd_brick(
     if (staged) {
       // ---- copy the box into LDS: whole head slices, 16 bytes per thread
       const int THW = TH * TW;
+      // r -> (rd, rh, rw) with two float multiplies instead of two runtime integer divisions (r < 2^12:
+      // (r + 0.5) / n is at least 0.5 / n away from an integer, far more than the float error)
+      const float inv_thw = 1.0f / static_cast<float>(THW), inv_tw = 1.0f / static_cast<float>(TW);
       for (int i = tid; i < rows * ROW_VECS; i += kBrickThreads) {
         const int r = i / ROW_VECS, v = i - r * ROW_VECS;
-        const int rd = r / THW, rr = r - rd * THW;
-        const int rh = rr / TW, rw = rr - rh * TW;
+        const int rd = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_thw), rr = r - rd * THW;
+        const int rh = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_tw), rw = rr - rh * TW;
         const long grow = start + (static_cast<long>(bd + rd) * H + (bh + rh)) * W + (bw + rw);
         const u32x4 x = *reinterpret_cast<const u32x4*>(value + ((b * S + grow) * M + m) * C + v * VEC);
         *reinterpret_cast<u32x4*>(tile + r * PITCH + v * 16) = x;
@@ -336,10 +339,11 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_query_brick(
 
     if (staged) {
       const int THW = TH * TW;
+      const float inv_thw = 1.0f / static_cast<float>(THW), inv_tw = 1.0f / static_cast<float>(TW);   // see the forward
       for (int i = tid; i < rows * ROW_VECS; i += kBrickThreads) {
         const int r = i / ROW_VECS, v = i - r * ROW_VECS;
-        const int rd = r / THW, rr = r - rd * THW;
-        const int rh = rr / TW, rw = rr - rh * TW;
+        const int rd = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_thw), rr = r - rd * THW;
+        const int rh = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_tw), rw = rr - rh * TW;
         const long grow = start + (static_cast<long>(bd + rd) * H + (bh + rh)) * W + (bw + rw);
         *reinterpret_cast<u32x4*>(tile + r * PITCH + v * 16) =
             *reinterpret_cast<const u32x4*>(value + ((b * S + grow) * M + m) * C + v * VEC);
