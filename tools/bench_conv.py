@@ -39,16 +39,19 @@ for name, ci, co, d, h, w, s in LAYERS:
         gy = torch.randn_like(y)
         wtr = wt.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, ci, co).to(torch.bfloat16).contiguous()
         res["hip_dgrad"] = round(t_ms(lambda: C.conv3d_k3_forward(gy, wtr, None, 1, dilated_input=(s == 2))), 3)
-        res["hip_wgrad_total"] = round(t_ms(lambda: C.conv3d_k3_wgrad(x, gy, s)), 3)
-        res["hip_wgrad_prep"] = round(t_ms(lambda: C.wgrad_operands(x, gy, s)), 3)
+        if s == 1 and C.lds_wgrad_supported(x, gy):
+            res["hip_wgrad_lds"] = round(t_ms(lambda: C.conv3d_k3_wgrad_lds(x, gy)), 3)     # what the model runs
+        else:
+            res["hip_wgrad_v1"] = round(t_ms(lambda: C.conv3d_k3_wgrad(x, gy, s)), 3)      # off by default
     else:
         conv = C.Conv3dK3(ci, co, 3, padding=1, bias=False).cuda()
         res["hip_fwd"] = round(t_ms(lambda: conv(x)), 3)
         y = conv(x); gy = torch.randn_like(y)
-        res["hip_wgrad_total"] = round(t_ms(lambda: C.conv3d_k3_wgrad(x, gy, 1)), 3)
+        xc = x.contiguous()
+        res["hip_wgrad_c1"] = round(t_ms(lambda: C.conv3d_c1_wgrad(xc, gy)), 3)
     flop = 2 * 27 * ci * co * y.shape[2] * y.shape[3] * y.shape[4] * 2
     res["fwd_TFs"] = round(flop / res["hip_fwd"] / 1e9, 1)
-    # MIOpen (NCDHW bf16, what the model currently runs)
+    # MIOpen (NCDHW bf16 operands)
     xn = x.contiguous().requires_grad_(ci > 1); wn = wt.to(torch.bfloat16).requires_grad_()
     res["miopen_fwd"] = round(t_ms(lambda: F.conv3d(xn, wn, stride=s, padding=1)), 3)
     yn = F.conv3d(xn, wn, stride=s, padding=1); gn = torch.randn_like(yn)
