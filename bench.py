@@ -116,9 +116,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward+loss+backward as one HIP graph (1.4 ms faster per step, host enqueue 9 ms "
+                         "instead of 56 ms; off by default: on ROCm 7.2 the replay of the refine-on step faults after "
+                         "33 launches, DESIGN.md section 8)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager step (default: fwd+loss+bwd captured in a HIP graph)")
+    ap.add_argument("--no-graph", action="store_true", help="eager step (the default; kept for compatibility)")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
@@ -157,12 +161,19 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
+    if not args.graph:
+        args.no_graph = True
     step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.rand(args.batch, 1, *cfg["volume_shape"], device=dev, generator=g)
     targets = DenseTargets.from_list(synthetic_targets(args.batch, cfg["num_classes"], seed=1 + rank, device=dev),
                                      cfg["num_classes"], dev)
+
+    def trace(msg):
+        if os.environ.get("TRANSOAR_BENCH_TRACE"):
+            torch.cuda.synchronize()
+            print("[bench] %s" % msg, file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,6 +183,7 @@ def main():
 
     step_mode = "eager"
     step(x, targets)                           # one eager step first (lazy init, MIOpen find-db lookups)
+    trace("first eager step done")
     if not args.no_graph:
         try:
             step.capture(x, targets)
@@ -183,8 +195,10 @@ def main():
             step_mode = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120],)
             step._graph = None
             step.reducer.overlap = True
-    for _ in range(args.warmup):
+    trace("capture done: %s" % step_mode)
+    for i in range(args.warmup):
         step(x, targets)
+        trace("warmup %d" % i)
     barrier()
     if step._graph is None:                    # eager: time the kernels over the timed steps themselves
         _native.profile_enable(True)
@@ -195,8 +209,14 @@ def main():
         h0 = time.perf_counter()
         total, _ = step(x, targets)
         host_s += time.perf_counter() - h0          # time the host needs to ENQUEUE a step (no sync)
+        if os.environ.get("TRANSOAR_BENCH_TRACE"):
+            if os.environ.get("TRANSOAR_BENCH_GC"):
+                import gc
+                gc.collect()
+            trace("timed step loss %.4f" % float(total))
     barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the
     # launch stream.  A replayed graph re-records nothing, so in graph mode they come from eager steps of
     # the same model state run right after the timed replays (kernel durations do not depend on how the
@@ -208,8 +228,9 @@ def main():
         prof_steps = 3
         _native.profile_enable(True)
         _native.profile_read()
-        for _ in range(prof_steps):
+        for i in range(prof_steps):
             step(x, targets)
+            trace("eager profile step %d" % i)
         torch.cuda.synchronize()
         step._graph = graph
     _native.profile_enable(False)

@@ -11,6 +11,8 @@ fp32 exactly like the single GEMM's accumulator.
 Same arithmetic contract as autocast's nn.Linear: bf16 operands, fp32
 accumulation, bf16 output; parameters and their gradients stay fp32.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -69,7 +71,8 @@ def token_linear(x, weight, bias=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
     bf16 autocast on the GPU with enough tokens, the stock one otherwise."""
     tokens = x.numel() // x.shape[-1]
-    if (x.is_cuda and tokens >= MIN_TOKENS and weight.dtype == torch.float32 and x.is_contiguous()
+    if (not os.environ.get("TRANSOAR_NO_TOKEN_LINEAR") and x.is_cuda and tokens >= MIN_TOKENS
+            and weight.dtype == torch.float32 and x.is_contiguous()
             and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
         return _TokenLinear.apply(x, weight, bias)
     return F.linear(x, weight, bias)
