@@ -83,6 +83,19 @@ static SideStream* side_stream() {
   return s.ok ? &s : nullptr;
 }
 
+// zero-fill as a kernel launch (16 bytes per thread; n16 = number of 16-byte pieces)
+__global__ __launch_bounds__(256) void msda3d_zero16(u32x4* __restrict__ p, long n16) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n16) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (getenv("TRANSOAR_MSDA_MEMSET_NODE")) return hipMemsetAsync(p, 0, bytes, st);
+  const long n16 = static_cast<long>((bytes + 15) / 16);           // every region is 16-byte padded
+  hipLaunchKernelGGL(msda3d_zero16, dim3(static_cast<unsigned>((n16 + 255) / 256)), dim3(256), 0, st,
+                     static_cast<u32x4*>(p), n16);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
@@ -269,7 +282,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   int* rank = reinterpret_cast<int*>(ws + w.rank);
   int* rec_item = reinterpret_cast<int*>(ws + w.rec_item);
   auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
-  TRANSOAR_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * w.n_scan, st));
+  TRANSOAR_CHECK_HIP(zero_async(count, sizeof(int) * w.n_scan, st));
   // cells per (batch, head) slab: needs the level shapes on the host; without them the binning
   // runs as its own kernel (msda3d_cell_count) after the gather
   long cells_per_slab = 0;
@@ -355,7 +368,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       }
       if (coarse_levels > 0) {
         ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, cst);
-        TRANSOAR_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * scratch_elems, cst));
+        TRANSOAR_CHECK_HIP(zero_async(scratch, sizeof(float) * scratch_elems, cst));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
         hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
                            go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl,

@@ -15,7 +15,6 @@ flag only works after a test harness has injected a core with
 oracle's torch restatement).  Without an injected core it raises.
 """
 import itertools
-import os
 import math
 import warnings
 
@@ -145,9 +144,7 @@ class MSDeformAttn(nn.Module):
         whd = input_spatial_shapes.flip(-1).to(offsets.dtype)
         locations = reference_points[:, :, None, :, None, :] + offsets / whd[None, None, None, :, None, :]
 
-        if self.use_cuda and os.environ.get("TRANSOAR_DUMMY_MSDA") and value.shape[1] == lq:
-            sampled = value.flatten(2) + 0.0 * (locations.sum() + weights.sum())      # debugging aid only
-        elif self.use_cuda:
+        if self.use_cuda:
             sampled = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                                  locations, weights, self.im2col_step)
         else:

@@ -182,8 +182,6 @@ class DecoderDefAttnBlock(nn.Module):
         return [tokens_to_map(m.contiguous(), shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
 
     def _fused_ok(self, tokens, pos_embeds):
-        if os.environ.get("TRANSOAR_NO_FUSED_TOKENS"):
-            return False
         return (tokens.is_cuda and tokens.dtype == torch.bfloat16 and tokens.is_contiguous()
                 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
                 and not any(p.requires_grad for p in pos_embeds)

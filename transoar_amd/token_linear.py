@@ -71,7 +71,7 @@ def token_linear(x, weight, bias=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
     bf16 autocast on the GPU with enough tokens, the stock one otherwise."""
     tokens = x.numel() // x.shape[-1]
-    if (not os.environ.get("TRANSOAR_NO_TOKEN_LINEAR") and x.is_cuda and tokens >= MIN_TOKENS
+    if (x.is_cuda and tokens >= MIN_TOKENS
             and weight.dtype == torch.float32 and x.is_contiguous()
             and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
         return _TokenLinear.apply(x, weight, bias)
