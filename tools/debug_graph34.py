@@ -40,10 +40,16 @@ x = torch.rand(2, 1, *cfg["volume_shape"], device="cuda", generator=g)
 targets = DenseTargets.from_list(synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda"), cfg["num_classes"], "cuda")
 step(x, targets)
 step.capture(x, targets)
+names = ["_backbone._decoder._refine.level_embed", "_backbone._decoder._refine.refine_def_attn.layers.0.linear1.weight",
+         "_backbone._decoder._refine.refine_def_attn.layers.1.norm2.weight", "_backbone._encoder._stages.0._block.0.weight",
+         "_neck.decoder.layers.0.linear1.weight", "_backbone._decoder._out.0.weight"]
+params = dict(model.named_parameters())
 for i in range(45):
     t, _ = step(x, targets)
     torch.cuda.synchronize()
     v = float(t)
+    if mode == "gradnorm" and (i < 6 or i > 28):
+        print(i + 1, "loss %.4f" % v, ["%.3e" % float(params[n].grad.float().norm()) for n in names], ["%.3e" % float(params[n].float().abs().max()) for n in names[:3]], flush=True)
     if v != v:
         print(mode, "NaN at replay", i + 1); break
 else:
