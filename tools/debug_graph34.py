@@ -22,6 +22,8 @@ from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, vi
 from transoar_amd.matcher import DenseTargets
 from transoar_amd.train_step import TrainStep
 from transoar_amd.transoarnet import TransoarNet, build_criterion
+if mode == "rocblas":
+    torch.backends.cuda.preferred_blas_library("cublas")      # rocBLAS instead of hipBLASLt
 cfg = visceral_config(refine=True, use_cuda=True)
 cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
 torch.manual_seed(0)
