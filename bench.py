@@ -28,6 +28,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see transoar_amd/__init__.py; before torch loads HIP
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -117,12 +119,12 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--graph", action="store_true",
-                    help="replay forward+loss+backward as one HIP graph (1.4 ms faster per step, host enqueue 9 ms "
-                         "instead of 56 ms; off by default: on ROCm 7.2 the replay of the refine-on step faults after "
-                         "33 launches, DESIGN.md section 8)")
+                    help="replay forward+loss+backward as one HIP graph: the default on one GPU (about 2 ms faster per "
+                         "step at K=10, host enqueue 9 ms instead of 56 ms).  With more than one rank the default is the "
+                         "eager step, whose bucketed all-reduce overlaps the backward (DESIGN.md sections 6 and 8)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager step (the default; kept for compatibility)")
+    ap.add_argument("--no-graph", action="store_true", help="eager step also on one GPU")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
@@ -134,6 +136,8 @@ def main():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if rank != 0:
+        os.dup2(2, 1)          # only rank 0 owns stdout (library banners of the other ranks go to stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
@@ -161,8 +165,8 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
-    if not args.graph:
-        args.no_graph = True
+    if not args.graph and (world > 1 or dist.is_initialized()):
+        args.no_graph = True                   # data-parallel default: eager step with the overlapped exchange
     step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -182,7 +186,15 @@ def main():
         torch.cuda.synchronize()
 
     step_mode = "eager"
-    step(x, targets)                           # one eager step first (lazy init, MIOpen find-db lookups)
+    if args.no_graph:
+        step(x, targets)                       # one eager step first (lazy init, MIOpen find-db lookups)
+    else:                                      # ... on the stream the capture will use (TrainStep.capture)
+        side = step.capture_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(x, targets)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
     trace("first eager step done")
     if not args.no_graph:
         try:
@@ -280,7 +292,7 @@ def main():
             except Exception as e:    # report, never fake
                 cpu = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port",
                        "sample": "cpu baseline leg failed: %r" % (e,)}
-        print(json.dumps({
+        line = json.dumps({
             "metric": "training-step CT volumes/s, 160x160x256 Focused-Decoder",
             "value": round(global_batch * args.steps / elapsed, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,9 +307,17 @@ def main():
                        "params": sum(p.numel() for p in model.parameters())},
             "loss": round(loss_value, 5), "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
             "roofline": roofline, "msda_kernels": kernels, "cpu_baseline": cpu,
-        }))
+        })
+    else:
+        line = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL printf()s a banner ("Librccl path : ...") into C stdio, which a pipe holds back until the
+    # process exits, i.e. AFTER Python's own output: drain it first so the JSON line is the last line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

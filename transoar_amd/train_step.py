@@ -13,6 +13,9 @@ weight decay 1e-4; optional gradient clipping), with these deliberate changes:
     normalisers are all-reduced so N data-parallel replicas equal one process
     on the concatenated batch.
 """
+import os
+import warnings
+
 import torch
 
 from .data_parallel import GradientAllReducer
@@ -81,7 +84,10 @@ class TrainStep:
             self._static_counts = self._local_counts(self._static_t)
             self.reducer.reduce_counts(self._static_counts)
         self.reducer.overlap = False
-        side = torch.cuda.Stream()
+        # warm-up AND capture on one and the same side stream: autograd's AccumulateGrad nodes remember the
+        # stream of the first backward; if the capture runs on another stream the engine inserts cross-stream
+        # waits into the captured graph (the "AccumulateGrad node's stream does not match" warning)
+        side = self.capture_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -91,14 +97,23 @@ class TrainStep:
         # the first replay is checked against this eager loss (same inputs and weights; only the
         # dropout masks differ) before the captured step is trusted: see _replay
         self._expect_total = float(eager_total)
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: this ROCm's pre-recorded graph packets "
+                          "corrupt the replayed step (DESIGN.md section 8); export it before the first HIP call")
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
         mode = "thread_local" if self.reducer.active else "global"
-        with torch.cuda.graph(graph, capture_error_mode=mode):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
             self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
         self._graph = graph
         return self
+
+    def capture_stream(self):
+        """The side stream every eager step before a capture should run on (see capture())."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     @staticmethod
     def _local_counts(targets):
