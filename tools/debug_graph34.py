@@ -1,5 +1,10 @@
-"""Which half of the MSDeformAttn op is involved in the corruption at the 34th graph replay?
-   python tools/debug_graph34.py {none|skip_bwd|skip_bwd_loc|skip_bwd_value}   (dev tool)"""
+"""What corrupts the captured refine-on training step at its 34th replay?  (dev tool; the answer is the
+runtime's graph packet capture: DESIGN.md section 8)
+   python tools/debug_graph34.py MODE [packet_capture]
+MODE: none | skip_bwd | skip_bwd_loc | skip_bwd_value | no_dropout | no_refine_dropout | gradnorm | rocblas |
+      side_first | no_first | accum | accum_eager | poison | poison_empty
+"packet_capture" as second argument leaves DEBUG_CLR_GRAPH_PACKET_CAPTURE at the runtime's default (on),
+which reproduces the corruption; without it the script switches it off like the package does."""
 import os, sys
 if "packet_capture" not in sys.argv[1:]:      # 'packet_capture' as 2nd argument leaves the runtime default on
     os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
