@@ -1,0 +1,59 @@
+"""The captured (HIP graph) training step must compute what the eager step computes -- on EVERY replay.
+
+ROCm 7.x's graph packet capture made the second and later replays of the refine-on step produce
+inf/garbage weight gradients while the first one was exact; the package switches
+it off (transoar_amd/__init__.py).  This test replays the captured forward+loss+backward without
+optimizer steps in between and compares gradients between replays and against an eager pass: weights and
+inputs are identical, only the dropout masks differ.
+"""
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_captured_step_replays_reproduce_eager_gradients():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import transoar_amd
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.matcher import DenseTargets
+    from transoar_amd.train_step import TrainStep
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+    assert transoar_amd.GRAPH_REPLAY_SAFE, "tests/conftest.py must switch graph packet capture off before HIP starts"
+    cfg = visceral_config(refine=True, use_cuda=True)
+    cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+    torch.manual_seed(0)
+    model = TransoarNet(cfg).cuda()
+    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.bfloat16, graph=True)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.rand(2, 1, *cfg["volume_shape"], device="cuda", generator=g)
+    targets = DenseTargets.from_list(synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda"),
+                                     cfg["num_classes"], "cuda")
+    params = {n: p for n, p in model.named_parameters() if p.requires_grad}
+
+    def grads():
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().clone() for n, p in params.items() if p.grad is not None}
+
+    step._eager_fwd_bwd(x, targets)
+    eager = grads()
+    step.capture(x, targets)
+    replays = []
+    for _ in range(4):
+        step._graph.replay()
+        replays.append(grads())
+    assert float(step._static_total) == float(step._static_total)          # not NaN
+    bad = []
+    for k, got in enumerate(replays):
+        for n, ref in eager.items():
+            if n not in got:
+                bad.append((k, n, "no gradient"))
+                continue
+            if not torch.isfinite(got[n]).all():
+                bad.append((k, n, "non-finite"))
+                continue
+            rn, gn = float(ref.norm()), float(got[n].norm())
+            # dropout changes individual gradients by tens of percent; garbage changes them by orders of magnitude
+            if rn > 1e-6 and not (0.25 * rn <= gn <= 4.0 * rn):
+                bad.append((k, n, rn, gn))
+    assert not bad, bad[:8]

@@ -3,10 +3,13 @@ runtime's graph packet capture: DESIGN.md section 8)
    python tools/debug_graph34.py MODE [packet_capture]
 MODE: none | skip_bwd | skip_bwd_loc | skip_bwd_value | no_dropout | no_refine_dropout | gradnorm | rocblas |
       side_first | no_first | accum | accum_eager | poison | poison_empty
-"packet_capture" as second argument leaves DEBUG_CLR_GRAPH_PACKET_CAPTURE at the runtime's default (on),
+"packet_capture" as second argument runs with DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 (the runtime's default),
 which reproduces the corruption; without it the script switches it off like the package does."""
 import os, sys
-if "packet_capture" not in sys.argv[1:]:      # 'packet_capture' as 2nd argument leaves the runtime default on
+if "packet_capture" in sys.argv[1:]:          # the runtime's default: reproduces the corruption
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
+    os.environ["TRANSOAR_TRUST_PACKET_CAPTURE"] = "1"
+else:
     os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

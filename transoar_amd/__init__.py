@@ -7,9 +7,16 @@ import os as _os
 # ROCm 7.x replays HIP graphs from AQL packets it pre-records at instantiation ("graph packet
 # capture").  With that on, the captured training step (train_step.TrainStep.capture) computes wrong
 # gradients from the second replay on and faults around the 34th; with it off the
-# same graph is exact.  The runtime reads the switch when libamdhip64 initialises, so it only takes
-# effect if this package (or the variable) comes before the first HIP call of the process.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# same graph is exact.  The runtime reads the switch at the first HIP call of the process (measured:
+# setting it after `import torch` but before any device work is early enough).
+import sys as _sys
+
+_torch = _sys.modules.get("torch")
+_hip_up = _torch is not None and _torch.cuda.is_initialized()      # the switch is read lazily, at the first HIP call
+if not _hip_up:
+    _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+#: False when the process initialised HIP with packet capture on: TrainStep.capture refuses then
+GRAPH_REPLAY_SAFE = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
 from . import _native  # noqa: F401  (fail loudly when the .so is missing)
 from . import msda as MSDA  # noqa: F401

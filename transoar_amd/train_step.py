@@ -14,7 +14,6 @@ weight decay 1e-4; optional gradient clipping), with these deliberate changes:
     on the concatenated batch.
 """
 import os
-import warnings
 
 import torch
 
@@ -97,9 +96,11 @@ class TrainStep:
         # the first replay is checked against this eager loss (same inputs and weights; only the
         # dropout masks differ) before the captured step is trusted: see _replay
         self._expect_total = float(eager_total)
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
-            warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: this ROCm's pre-recorded graph packets "
-                          "corrupt the replayed step (DESIGN.md section 8); export it before the first HIP call")
+        from . import GRAPH_REPLAY_SAFE
+        if not GRAPH_REPLAY_SAFE and not os.environ.get("TRANSOAR_TRUST_PACKET_CAPTURE"):
+            raise RuntimeError("HIP was initialised with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: this ROCm's pre-recorded "
+                               "graph packets corrupt the replayed step (DESIGN.md section 8); export "
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or import transoar_amd before the first HIP call")
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
