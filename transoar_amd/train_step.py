@@ -65,8 +65,8 @@ class TrainStep:
         return total, losses
 
     # ---- captured-graph mode ------------------------------------------------------------------
-    # The eager step is host-bound on one MI355X (~2000 kernel launches: 84 ms of enqueue for 80 ms
-    # of GPU work), so forward + criterion + backward are captured once into a HIP graph over static
+    # The eager step is close to host-bound on one MI355X (~2000 kernel launches: 56 ms of enqueue for
+    # 60 ms of GPU work), so forward + criterion + backward are captured once into a HIP graph over static
     # input buffers and replayed; the gradient exchange (eager, on the flat buckets, after the
     # replay -- no collective inside the graph) and the fused optimizer follow.
     def capture(self, data, targets, warmup=3):
