@@ -72,6 +72,7 @@ enum {
 #define TRANSOAR_MSDA3D_FORCE_GENERIC 1u  /* skip the vectorised kernels   */
 #define TRANSOAR_MSDA3D_NO_BRICK 4u        /* per-item / voxel-stationary kernels even where the LDS-tiled ones apply */
 #define TRANSOAR_MSDA3D_FORK 8u             /* backward: run the coarse-level grad_value walk on an internal side stream */
+#define TRANSOAR_MSDA3D_NO_MMA 16u            /* forward: LDS-tiled per-corner kernel instead of the matrix-core gather */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*

@@ -385,3 +385,79 @@ def test_forked_grad_value_walk_matches_serial(MSDA):
     for a, b in zip(*res):
         assert relerr(a, b) <= TOL[torch.bfloat16]
 
+
+
+# ---------------------------------------------------------------------------
+# the timed kernels at the sizes they are timed on: 16-bit storage, N = 2, queries = the pyramid's voxels
+# (flagship S = Lq = 117 000 with 4 levels; AMOS S = Lq = 18 688 with 3 levels) -- the matrix-core forward
+# gather (msda3d_mma.hpp) and the LDS brick / tile / cell kernels of the backward
+# ---------------------------------------------------------------------------
+def _full_size_case(geom, dist):
+    levels = _inputs.VISCERAL_LEVELS if geom == "visceral" else _inputs.AMOS_LEVELS
+    jitter = 0.0 if dist == "init" else 0.3
+    value, shapes, lsi, loc, attn = _inputs.model_like_inputs(11, 2, levels, device="cuda", jitter=jitter)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    if dist == "uniform":      # ops/test.py's distribution: no locality -> per-corner path of the gather, tile and
+        loc = torch.rand(loc.shape, device="cuda", generator=g)          # histogram overflow fallbacks of the bricks
+    elif dist == "oob":        # wide offsets, a good part of the points outside [0,1]: skipped points, border cells
+        loc = (loc + (torch.rand(loc.shape, device="cuda", generator=g) - 0.5) * 0.5).contiguous()
+    return value, shapes, lsi, loc, attn
+
+
+@pytest.mark.parametrize("geom", ["visceral", "amos"])
+@pytest.mark.parametrize("dist", ["model", "init", "uniform", "oob"])
+@pytest.mark.parametrize("vdt", [torch.bfloat16])
+def test_full_size_16bit_kernels_vs_c_oracle(MSDA, geom, dist, vdt):
+    """>= 1000 sampled queries of out / grad_loc / grad_attn against the scalar C oracle run on the same
+    bf16-rounded inputs; grad_value through the adjoint identity <grad_value, u> = <grad_out, forward(u)>
+    (forward being oracle-checked here) and against the voxel-stationary pull kernel."""
+    value, shapes, lsi, loc, attn = _full_size_case(geom, dist)
+    v = value.to(vdt)
+    N, S, M, C = v.shape
+    g = torch.Generator(device="cuda").manual_seed(23)
+    go = torch.randn(N, S, M * C, device="cuda", generator=g).to(vdt)
+    MSDA.flags = 0
+    out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+    assert not torch.isnan(out.float()).any() and not torch.isnan(gv.float()).any()
+    # every level and both border regions are represented: first/last rows of each level + random rows
+    edges = torch.cat([torch.arange(int(s), int(s) + 24) for s in lsi.tolist()] + [torch.arange(S - 24, S)])
+    pick = torch.cat([edges, torch.randint(0, S, (1100,), generator=torch.Generator().manual_seed(3))]).unique()
+    f = lambda t: t.float().cpu().numpy()
+    pc = pick.cuda()
+    ref = c_oracle.forward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]), f(attn[:, pc]))
+    assert relerr(out[:, pc], torch.from_numpy(ref)) <= TOL[vdt]
+    _, rgl, rga = c_oracle.backward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]),
+                                    f(attn[:, pc]), f(go[:, pc]))
+    assert relerr(gl[:, pc], torch.from_numpy(rgl)) <= 1e-4
+    assert relerr(ga[:, pc], torch.from_numpy(rga)) <= 1e-4
+    # grad_value: adjoint of the (linear in value) forward
+    u = torch.randn(v.shape, device="cuda", generator=g).to(vdt)
+    fu = MSDA.ms_deform_attn_forward(u, shapes, lsi, loc, attn, 64)
+    lhs = float((gv.double() * u.double()).sum())
+    rhs = float((go.double() * fu.double()).sum())
+    scale = float((go.double().abs() * fu.double().abs()).sum())
+    assert abs(lhs - rhs) <= 2e-3 * scale / (S ** 0.5)      # both sides carry independent 2^-9 roundings of ~N*S*M*C terms
+    # ... and element-wise against the kernels that take no host shapes (oracle-checked on the small shapes above)
+    MSDA.locality_hint = False
+    try:
+        gv2 = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)[0]
+        out2 = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
+    finally:
+        MSDA.locality_hint = True
+    assert relerr(gv, gv2) <= TOL[vdt]
+    assert relerr(out, out2) <= TOL[vdt]
+
+
+def test_matrix_core_gather_matches_per_corner_brick_kernel(MSDA):
+    """flag 16 forces the LDS per-corner brick forward; both must agree to output rounding on every element
+    (f16 and bf16, flagship geometry at batch 1)."""
+    value, shapes, lsi, loc, attn = _inputs.model_like_inputs(4, 1, _inputs.VISCERAL_LEVELS, device="cuda")
+    for vdt in (torch.bfloat16, torch.float16):
+        v = value.to(vdt)
+        res = []
+        for fl in (0, 16):
+            MSDA.flags = fl
+            res.append(MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64))
+        MSDA.flags = 0
+        assert relerr(res[0], res[1]) <= TOL[vdt]

@@ -13,6 +13,7 @@
 #include "../../include/transoar_msda3d.h"
 #include "msda3d_common.hpp"
 #include "msda3d_brick.hpp"
+#include "msda3d_mma.hpp"
 #include "msda3d_tile.hpp"
 #include "msda3d_gather.hpp"
 #include "msda3d_generic.hpp"
@@ -194,6 +195,20 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
   // LDS-tiled brick kernel: queries are the pyramid's voxels (Lq == S), host knows the shapes,
   // 64 channels per head, 4 points per level (the refine block's configuration)
   // (16-bit storage only: an fp32 box of the finest level does not fit the 48 KiB tile)
+  if constexpr (sizeof(VT) == 2) {
+    // matrix-core gather: one wave per 32 queries (2x4x4 sub-brick) and head
+    bool small = d.L <= kMmaLevels;
+    for (int l = 0; small && l < d.L; ++l) small = order.D[l] <= 1000 && order.H[l] <= 1000 && order.W[l] <= 1000;
+    if (lg >= 0 && order.enabled && small && d.C == 64 && d.P == 4 &&
+        !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
+      ProfScope prof(TRANSOAR_PROF_FWD, st);
+      const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 4;
+      const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
+      hipLaunchKernelGGL((msda3d_fwd_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
+                         v, lo, at, o, d.S, d.M, d.L, vbytes, n_wave, order);
+      return static_cast<int>(hipGetLastError());
+    }
+  }
   if (lg >= 0 && order.enabled && d.C == 64 && d.P == 4 && sizeof(VT) == 2 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
     ProfScope prof(TRANSOAR_PROF_FWD, st);
     const long n_wg = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M;

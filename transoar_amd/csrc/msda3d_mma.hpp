@@ -1,0 +1,425 @@
+// Forward gather of MSDeformAttn-3D on the matrix cores (gfx950).
+//
+// out[q, :] = sum over the sampling points of q of  a * w_corner * value[row, :]  is, for a group of
+// neighbouring queries, a product  OUT^T[c, q] = V^T[c, r] . Wt[r, q]  of the level's value rows r inside
+// the group's bounding box with a 32 x R weight matrix that has <= 32 non-zeros per query and level.  The
+// per-corner formulation (msda3d_brick.hpp) spends 12 000 VALU instructions per wave on unpacking bf16
+// rows and multiplying them one corner at a time; here the rows never leave their 16-bit storage form:
+//
+//   * one WAVE owns 32 queries (a 2x4x4 sub-brick of the pyramid) of one head; no workgroup barriers,
+//   * per level it reduces the bounding box of the corner voxels its queries touch and walks the box in
+//     K-blocks of 64 rows: the rows go global -> registers -> LDS as whole 128-byte head slices (prefetched
+//     one block ahead, across levels), every lane adds its 16 corner weights (2 points x 8 corners) into a
+//     32 x 64 fp32 weight block in LDS (read-add-write, one round per point: points of a query may share corners),
+//   * per 16 rows: B = the weight block rows split into two bf16 terms (hi + lo, so the weights keep
+//     16 mantissa bits: fp32-accurate results), A = V^T read straight out of the row-major LDS rows by the
+//     transpose read ds_read_b64_tr_b16, 4 v_mfma_f32_32x32x16 (2 channel halves x hi/lo), fp32 accumulate,
+//   * D comes out as [channel][query]: a lane holds 4 consecutive channels of its query per register
+//     quad and stores 8 bytes at a time.
+// A level whose box is larger than kMmaDenseRows rows (non-local sampling) is gathered corner by corner
+// from global memory into the same accumulators.
+//
+// Dense work: 2 * 32 * R * 64 flops per wave and level on the MFMA pipe instead of 2 * 32 * 32 * 64 on the
+// VALU; R is 130..250 for the self-attention pattern of the refine block.
+#pragma once
+#include "msda3d_common.hpp"
+
+namespace transoar {
+
+constexpr int kMmaKB = 64;              // value rows per K-block
+constexpr int kMmaVP = 144;             // bytes per staged row: 128 + 16 (16-byte aligned, spreads banks)
+constexpr int kMmaWRows = kMmaKB + 1;   // weight block [column][query]: 64 columns + one spare row for entries outside the block
+constexpr int kMmaDenseRows = 1024;     // larger boxes take the per-corner path
+constexpr int kMmaLevels = 4;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename VT> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  // w = hi + lo (+ 2^-16 relative): hi = w truncated to bf16, lo = (w - hi) truncated to bf16
+  static __device__ __forceinline__ void split(const float (&w)[8], s16x8& hi, s16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned u0 = __float_as_uint(w[2 * i]), u1 = __float_as_uint(w[2 * i + 1]);
+      h[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+      const unsigned r0 = __float_as_uint(w[2 * i] - __uint_as_float(u0 & 0xffff0000u));
+      const unsigned r1 = __float_as_uint(w[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u));
+      l[i] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+    }
+    hi = __builtin_bit_cast(s16x8, u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(s16x8, u32x4{l[0], l[1], l[2], l[3]});
+  }
+};
+template <> struct Mma<f16_t> {
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void split(const float (&w)[8], s16x8& hi, s16x8& lo) {
+    f16x8_t h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i] = static_cast<_Float16>(w[i]);
+      l[i] = static_cast<_Float16>(w[i] - static_cast<float>(h[i]));
+    }
+    hi = __builtin_bit_cast(s16x8, h);
+    lo = __builtin_bit_cast(s16x8, l);
+  }
+};
+
+// ---- wave-wide minimum of two packed int16 (v_pk_min_i16), result wave-uniform: DPP inside the rows of
+// 16 lanes, row_bcast15 / row_bcast31 across them, the total ends up in lane 63
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wave_min_pk16(int v) {
+#define TRANSOAR_DPP_STEP(CTRL, ROWMASK)                                                        \
+  {                                                                                             \
+    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false);                 \
+    v = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(s16x2, v), __builtin_bit_cast(s16x2, o))); \
+  }
+  TRANSOAR_DPP_STEP(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  TRANSOAR_DPP_STEP(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  TRANSOAR_DPP_STEP(0x141, 0xf)   // row_half_mirror
+  TRANSOAR_DPP_STEP(0x140, 0xf)   // row_mirror: every lane holds its row's minimum
+  TRANSOAR_DPP_STEP(0x142, 0xa)   // row_bcast15 into rows 1 and 3
+  TRANSOAR_DPP_STEP(0x143, 0xc)   // row_bcast31 into rows 2 and 3
+#undef TRANSOAR_DPP_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+
+// compile-time loop: the per-level state below must stay in registers (constant indices only)
+template <int I> struct IntC { static constexpr int value = I; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// geometry of one sampling point, kept for the whole kernel (5 registers)
+struct MmaPoint {
+  int dhw;            // (d0+1) | (h0+1) << 10 | (w0+1) << 20 ; 0x3fffffff marks a skipped point
+  float ld, lh, lw, a;
+};
+struct MmaBox {       // wave-uniform: corner-voxel bounding box of the wave's points on one level
+  int bd, bh, bw, TD, TH, TW;
+};
+
+template <typename VT, typename LT>
+__global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
+    const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
+    VT* __restrict__ out, int S, int M, int L, unsigned value_bytes, long n_units, BrickOrder order) {
+  constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
+  __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
+  __shared__ __attribute__((aligned(16))) float wbuf[WR * 32];      // [column][query]: query-fastest, bank = query
+
+  const long u = xcd_contiguous_block(blockIdx.x, n_units);
+  if (u < 0) return;
+  const int lane = threadIdx.x;
+  const int j = lane & 31, kg = lane >> 5;
+  const int sb = static_cast<int>(u & 3);
+  const long t1 = u >> 2;
+  const int m = static_cast<int>(t1 % M);
+  const long t2 = t1 / M;
+  const int bricks = order.pad_start[order.L] >> 7;
+  const int brick = bricks - 1 - static_cast<int>(t2 % bricks);      // coarse levels first: their boxes are the big ones
+  const long b = t2 / bricks;
+  const int slot = (2 * (sb >> 1) + (j >> 4)) * 32 + ((j >> 2) & 3) * 8 + 4 * (sb & 1) + (j & 3);
+  const int s = brick_slot_to_row(order, brick * kBrickSlots + slot);
+  const bool live = s >= 0;
+  const long item = live ? (b * S + s) * M + m : 0;
+  const int LP = L * P;
+  const unsigned row_bytes = static_cast<unsigned>(M) * C * sizeof(VT);
+  const unsigned head_off = static_cast<unsigned>((b * S * M + m) * C * sizeof(VT));
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<VT*>(value), 0, static_cast<int>(value_bytes), 0x00020000);
+
+  // ---- geometry of this lane's two points (2*kg, 2*kg+1) on every level, boxes per level
+  MmaPoint pt[kMmaLevels][2];
+  MmaBox box[kMmaLevels];
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    box[l] = MmaBox{0, 0, 0, 0, 0, 0};
+    if (l >= L) return;
+    const int D = order.D[l], H = order.H[l], W = order.W[l];
+    int lo_d = 32767, lo_h = 32767, lo_w = 32767, hi_d = -1, hi_h = -1, hi_w = -1;
+    float lx[2] = {0.f, 0.f}, ly[2] = {0.f, 0.f}, lz[2] = {0.f, 0.f}, la[2] = {0.f, 0.f};
+    if (live) {
+      const long jx = item * LP + l * P + 2 * kg;          // even: the two points are 24 + 8 contiguous bytes
+      if constexpr (sizeof(LT) == 4) {
+        const float2 q0 = *reinterpret_cast<const float2*>(loc + 3 * jx), q1 = *reinterpret_cast<const float2*>(loc + 3 * jx + 2),
+                     q2 = *reinterpret_cast<const float2*>(loc + 3 * jx + 4), qa = *reinterpret_cast<const float2*>(attn + jx);
+        lx[0] = q0.x; ly[0] = q0.y; lz[0] = q1.x; lx[1] = q1.y; ly[1] = q2.x; lz[1] = q2.y;
+        la[0] = qa.x; la[1] = qa.y;
+      } else {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          lx[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi)));
+          ly[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 1));
+          lz[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 2));
+          la[pi] = static_cast<float>(Elem<LT>::ld(attn + jx + pi));
+        }
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      MmaPoint g{0x3fffffff, 0.f, 0.f, 0.f, 0.f};
+      const float w_im = pixel_coord(lx[pi], W), h_im = pixel_coord(ly[pi], H), d_im = pixel_coord(lz[pi], D);
+      if (live && d_im > -1.f && h_im > -1.f && w_im > -1.f && d_im < D && h_im < H && w_im < W) {
+        const float fd = floorf(d_im), fh = floorf(h_im), fw = floorf(w_im);
+        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
+        g.dhw = (d0 + 1) | ((h0 + 1) << 10) | ((w0 + 1) << 20);
+        g.ld = d_im - fd; g.lh = h_im - fh; g.lw = w_im - fw; g.a = la[pi];
+        lo_d = min(lo_d, max(d0, 0)); hi_d = max(hi_d, min(d0 + 1, D - 1));
+        lo_h = min(lo_h, max(h0, 0)); hi_h = max(hi_h, min(h0 + 1, H - 1));
+        lo_w = min(lo_w, max(w0, 0)); hi_w = max(hi_w, min(w0 + 1, W - 1));
+      }
+      pt[l][pi] = g;
+    }
+    // six wave-wide extrema as three packed 16-bit minima (maxima negated)
+    const int r0 = wave_min_pk16(pack16(lo_d, lo_h)), r1 = wave_min_pk16(pack16(lo_w, -hi_d)), r2 = wave_min_pk16(pack16(-hi_h, -hi_w));
+    hi_d = -(r1 >> 16);
+    if (hi_d < 0) return;                         // no valid point of this wave on the level
+    lo_d = static_cast<short>(r0); lo_h = r0 >> 16; lo_w = static_cast<short>(r1);
+    hi_h = -static_cast<int>(static_cast<short>(r2)); hi_w = -(r2 >> 16);
+    box[l] = MmaBox{lo_d, lo_h, lo_w, hi_d - lo_d + 1, hi_h - lo_h + 1, hi_w - lo_w + 1};
+  });
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  for (int i = lane; i < WR * 32 / 4; i += 64) reinterpret_cast<float4*>(wbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < KB * VP / 16; i += 64) reinterpret_cast<float4*>(vbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
+
+  // rows [kb*KB, kb*KB + KB) of level l's box -> 8 x 16 bytes per lane (rows past the box: zeros).  Lane i
+  // computes the byte offset of row kb*KB + i once; the 8 lanes that fetch a row get it through ds_bpermute.
+  const int st_row = lane >> 3, st_vec = lane & 7;
+  auto load_block = [&](auto lc, int kb, u32x4 (&pre)[8]) {
+    constexpr int l = decltype(lc)::value;
+    const MmaBox bx = box[l];
+    const int H = order.H[l], W = order.W[l], start = order.start[l];
+    const int THW = bx.TH * bx.TW, R = bx.TD * THW;
+    // r -> (rd, rh, rw) by float reciprocals: (r + 0.5) / n is >= 0.5 / n away from an integer, far more than
+    // the float error for r < 2^12
+    const float inv_thw = __builtin_amdgcn_rcpf(static_cast<float>(THW)), inv_tw = __builtin_amdgcn_rcpf(static_cast<float>(bx.TW));   // 1 ulp
+    const int r = kb * KB + lane;
+    const int rd = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_thw), rr = r - __mul24(rd, THW);
+    const int rh = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_tw), rw = rr - __mul24(rh, bx.TW);
+    const int grow = start + __mul24(__mul24(bx.bd + rd, H) + (bx.bh + rh), W) + (bx.bw + rw);
+    const unsigned past = static_cast<unsigned>((R - 1 - r) >> 31);             // all ones for rows past the box
+    const int row_off = static_cast<int>((head_off + __umul24(static_cast<unsigned>(grow), row_bytes)) | (past & 0xfffffff0u));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned off = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute((it * 8 + st_row) * 4, row_off)) + st_vec * 16u;
+      pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+  };
+
+  u32x4 pre[8];
+  bool have_pre = false;
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if (l >= L || box[l].TD == 0) return;
+    const MmaBox bx = box[l];
+    const int D = order.D[l], H = order.H[l], W = order.W[l];
+    const int THW = bx.TH * bx.TW, R = bx.TD * THW;
+
+    // ---- weight-matrix entries of this lane: its 2 points x 8 corners.  ecol = word offset of the entry in
+    // a weight block that would hold the whole box, column-major ([column][query]): column * 32 + j; a
+    // corner outside the level gets a negative one.  ewt = a * trilinear weight.
+    int ecol[16];
+    float ewt[16];
+    int near = 0;          // do the partner lane's points (same query, points +2) touch a corner of ours?
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const MmaPoint g = pt[l][pi];
+      const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
+      const bool okp = g.dhw != 0x3fffffff;
+      const int cb = (__mul24(__mul24(d0 - bx.bd, bx.TH) + (h0 - bx.bh), bx.TW) + (w0 - bx.bw)) * 32 + j;
+      const bool vd[2] = {okp && static_cast<unsigned>(d0) < static_cast<unsigned>(D), okp && static_cast<unsigned>(d0 + 1) < static_cast<unsigned>(D)};
+      const bool vh[2] = {static_cast<unsigned>(h0) < static_cast<unsigned>(H), static_cast<unsigned>(h0 + 1) < static_cast<unsigned>(H)};
+      const bool vw[2] = {static_cast<unsigned>(w0) < static_cast<unsigned>(W), static_cast<unsigned>(w0 + 1) < static_cast<unsigned>(W)};
+      const float wd[2] = {g.a * (1.f - g.ld), g.a * g.ld}, wh[2] = {1.f - g.lh, g.lh}, ww[2] = {1.f - g.lw, g.lw};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = c >> 1, dh = c & 1;
+        const float f = wd[dd] * wh[dh];
+        const int col = cb + (dd ? THW * 32 : 0) + (dh ? bx.TW * 32 : 0);
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          ecol[pi * 8 + 2 * c + dw] = (vd[dd] && vh[dh] && vw[dw]) ? col + 32 * dw : -64;
+          ewt[pi * 8 + 2 * c + dw] = f * ww[dw];
+        }
+      }
+      // point pi of lane ^ 32 is added in the same round as ours: safe only if no corner is shared
+      const int odhw = __builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, g.dhw);
+      const int od = (odhw & 1023) - 1 - d0, oh = ((odhw >> 10) & 1023) - 1 - h0, ow = ((odhw >> 20) & 1023) - 1 - w0;
+      near |= (okp && odhw != 0x3fffffff && abs(od) <= 1 && abs(oh) <= 1 && abs(ow) <= 1) ? 1 : 0;
+    }
+    const bool shared = __any(near);     // wave-uniform: the two halves of the wave must take turns
+
+    if (R > kMmaDenseRows) {
+      // ---- non-local level: corner by corner from global memory.  D layout: this lane holds channels
+      // tile*32 + 8*bq + 4*kg + (0..3) of query j; it needs all 4 points of the query: its own two and
+      // those of lane ^ 32.
+#pragma unroll 1
+      for (int sp = 0; sp < 4; ++sp) {
+        {
+          const int side = sp >> 1;
+          MmaPoint g = (sp & 1) ? pt[l][1] : pt[l][0];
+          if (side) {
+            g.dhw = __shfl_xor(g.dhw, 32, 64);
+            g.ld = __shfl_xor(g.ld, 32, 64); g.lh = __shfl_xor(g.lh, 32, 64);
+            g.lw = __shfl_xor(g.lw, 32, 64); g.a = __shfl_xor(g.a, 32, 64);
+          }
+          if (g.dhw == 0x3fffffff) continue;
+          const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
+#pragma unroll 1
+          for (int k = 0; k < 8; ++k) {
+            const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+            const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
+            if (static_cast<unsigned>(d) >= static_cast<unsigned>(D) || static_cast<unsigned>(h) >= static_cast<unsigned>(H) ||
+                static_cast<unsigned>(w) >= static_cast<unsigned>(W))
+              continue;
+            const float wv = g.a * ((dd ? g.ld : 1.f - g.ld) * (dh ? g.lh : 1.f - g.lh)) * (dw ? g.lw : 1.f - g.lw);
+            const long grow = order.start[l] + (static_cast<long>(d) * H + h) * W + w;
+            const VT* src = value + ((b * S + grow) * M + m) * C + 4 * kg;
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+              for (int bq = 0; bq < 4; ++bq) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(src + tile * 32 + 8 * bq);
+                const u32x4 r4{raw.x, raw.y, 0u, 0u};
+                float vv[8];
+                Elem<VT>::unpack(r4, vv);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  if (tile == 0) acc0[4 * bq + t] += wv * vv[t];
+                  else acc1[4 * bq + t] += wv * vv[t];
+                }
+              }
+            }
+          }
+        }
+      }
+      have_pre = false;
+      return;
+    }
+
+    const int nblk = (R + KB - 1) / KB;
+    if (!have_pre) load_block(lc, 0, pre);
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int k0 = kb * KB;
+      const int nch = (min(KB, R - k0) + 15) >> 4;          // 16-row chunks of this block
+      // ---- staged rows -> LDS (rows past the box arrive as zeros)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+      if (nch > 2) {
+#pragma unroll
+        for (int it = 4; it < 8; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+      }
+      // ---- prefetch the next block (of this level, or the first of the next one)
+      have_pre = false;
+      if (kb + 1 < nblk) {
+        load_block(lc, kb + 1, pre);
+        have_pre = true;
+      } else if constexpr (l + 1 < kMmaLevels) {
+        if (l + 1 < L && box[l + 1].TD != 0) {
+          const MmaBox nb = box[l + 1];
+          if (nb.TD * nb.TH * nb.TW <= kMmaDenseRows) {
+            load_block(IntC<l + 1>{}, 0, pre);
+            have_pre = true;
+          }
+        }
+      }
+      // ---- weight block: W[col][j] += weight.  The 8 corners of one point are distinct words; corners of
+      // different points of the query may coincide: one read-add-write round per point (LDS float atomics
+      // run at a lane per clock), and the two lanes of a query take turns when their points are neighbours.
+      // No predication: an entry outside this block goes to the spare row (column KB); every access of the
+      // wave is one word per bank.
+      int wad[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        wad[e] = static_cast<int>(min(static_cast<unsigned>(ecol[e] - k0 * 32), static_cast<unsigned>(KB * 32 + j)));
+      auto add_round = [&](auto pic, int turn) {         // turn: -1 = every lane, else the half whose turn it is
+        constexpr int pi = decltype(pic)::value;
+        int ad[8];
+        float prev[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ad[q] = (turn < 0 || kg == turn) ? wad[pi * 8 + q] : KB * 32 + j;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) prev[q] = wbuf[ad[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wbuf[ad[q]] = prev[q] + ewt[pi * 8 + q];
+      };
+      if (!shared) {
+        add_round(IntC<0>{}, -1);
+        add_round(IntC<1>{}, -1);
+      } else {
+        add_round(IntC<0>{}, 0);
+        add_round(IntC<1>{}, 0);
+        add_round(IntC<0>{}, 1);
+        add_round(IntC<1>{}, 1);
+      }
+      // ---- pairs of 16-row chunks on the matrix cores (an odd last chunk runs on zero weights)
+      for (int kc = 0; kc < nch; kc += 2) {
+        s16x8 bhi[2], blo[2], a0[2], a1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float* wcol = wbuf + ((kc + h) * 16 + 8 * kg) * 32 + j;
+          float wv[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) wv[t] = wcol[32 * t];
+          Mma<VT>::split(wv, bhi[h], blo[h]);
+          // A = V^T: lane supplies row (lane & 15) >> 2 of its group's 4-row set, 4 channels; receives its channel's column
+          const unsigned char* abase = vbuf + ((kc + h) * 16 + 8 * kg + ((lane & 15) >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const s16x4 a00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(abase));
+          const s16x4 a01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(abase + 4 * VP));
+          const s16x4 a10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(abase + 64));
+          const s16x4 a11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(abase + 4 * VP + 64));
+          a0[h] = __builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7);
+          a1[h] = __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc0 = Mma<VT>::mfma(a0[h], bhi[h], acc0);
+          acc1 = Mma<VT>::mfma(a1[h], bhi[h], acc1);
+          acc0 = Mma<VT>::mfma(a0[h], blo[h], acc0);
+          acc1 = Mma<VT>::mfma(a1[h], blo[h], acc1);
+        }
+      }
+      // ---- clear the weight entries again
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wbuf[wad[e]] = 0.f;
+    }
+  });
+
+  if (live) {
+    VT* dst = out + item * C + 4 * kg;
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v[t] = tile == 0 ? acc0[4 * bq + t] : acc1[4 * bq + t];
+          v[4 + t] = 0.f;
+        }
+        const u32x4 pk = Elem<VT>::pack(v);
+        *reinterpret_cast<uint2*>(dst + tile * 32 + 8 * bq) = uint2{pk[0], pk[1]};
+      }
+    }
+  }
+}
+
+}  // namespace transoar
