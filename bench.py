@@ -205,8 +205,7 @@ def main():
             import traceback
             traceback.print_exc()
             step_mode = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120],)
-            step._graph = None
-            step.reducer.overlap = True
+            step.drop_graph()
     trace("capture done: %s" % step_mode)
     for i in range(args.warmup):
         step(x, targets)

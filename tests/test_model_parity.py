@@ -188,7 +188,7 @@ def test_g7_whole_model_and_criterion(golden_dir, debug_core, device, tag, refin
 def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     """The bf16-autocast TRAINING path on the GPU (hand-written conv / InstanceNorm / layout / token
     kernels, which the fp32 golden tests above do not take) must back-propagate into every parameter
-    the fp32 path reaches, with gradients pointing the same way.  (A raw kernel call in a tracked
+    the fp32 path reaches and stay within the stated bf16 tolerances of outputs, losses and gradients.  (A raw kernel call in a tracked
     forward once cut the graph between FPN decoder and encoder without failing any parity test.)"""
     _skip_if_no_gpu("cuda")
     from transoar_amd.config import synthetic_targets
@@ -205,7 +205,7 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     targets = synthetic_targets(1, 20, seed=1, device="cuda")
     crit = build_criterion(cfg)
     coefs = cfg["loss_coefs"]
-    grads = {}
+    grads, outs, loss_vals = {}, {}, {}
     old_min = Conv3dK3.min_voxels
     try:
         for mode in ("fp32", "bf16"):
@@ -216,24 +216,37 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
                 losses = crit(out, targets, None, net._anchors)
                 total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
             total.backward()
+            outs[mode] = {k: out[k].detach().float() for k in ("pred_logits", "pred_boxes")}
+            loss_vals[mode] = {k: float(v) for k, v in losses.items()}
             grads[mode] = {n: (None if p.grad is None else p.grad.detach().double().flatten().cpu())
                            for n, p in net.named_parameters()}
     finally:
         Conv3dK3.min_voxels = old_min
     missing = [n for n, g in grads["bf16"].items() if g is None and grads["fp32"][n] is not None]
     assert not missing, missing
-    low, cosines = [], []
+    # ---- stated bf16 tolerances of the model, against the fp32 run of the same kernels' host model on the
+    # same weights (which the g7 test pins to the reference at 1e-4).  bf16 carries 8 mantissa bits and every
+    # activation of the 12-conv backbone + 2 refine layers + 3 decoder layers is rounded to it:
+    #   pred_boxes (values in [0,1])        max abs error   <= 1e-2
+    #   pred_logits                          max error       <= 3e-2 of the largest |logit| (+ 1e-2 abs)
+    #   each of the 11 loss scalars          relative error  <= 3e-2 (+ 2e-3 abs)
+    #   parameter gradients, relative L2     median <= 6e-2, 90 % of the tensors <= 0.35
+    # (the first encoder convolutions sit behind 12 InstanceNorms: their gradients are ill-conditioned --
+    # >10 % checksum drift between two fp32 CPU runs, tests/test_data_parallel.py -- hence the tail bound)
+    o32, o16 = outs["fp32"], outs["bf16"]
+    assert float((o16["pred_boxes"].float() - o32["pred_boxes"]).abs().max()) <= 1e-2
+    lmax = float(o32["pred_logits"].abs().max())
+    assert float((o16["pred_logits"].float() - o32["pred_logits"]).abs().max()) <= 3e-2 * lmax + 1e-2
+    for k, v32 in loss_vals["fp32"].items():
+        assert abs(loss_vals["bf16"][k] - v32) <= 3e-2 * abs(v32) + 2e-3, (k, loss_vals["bf16"][k], v32)
+    rel = []
     for n, g32 in grads["fp32"].items():
         g16 = grads["bf16"][n]
         if g32 is None or float(g32.norm()) < 1e-9:
             continue
-        cos = float((g32 * g16).sum() / (g32.norm() * g16.norm() + 1e-300))
-        cosines.append(cos)
-        if cos < 0.3:
-            low.append((n, round(cos, 3)))
-    # the first encoder convolutions sit behind 12 InstanceNorms: their gradients are ill-conditioned
-    # (0.65-0.9 cosine between bf16 and fp32 here, >10 % checksum drift between two fp32 CPU runs,
-    # tests/test_data_parallel.py), and a conv weight directly in front of a norm layer has an almost
-    # vanishing true gradient -- the bounds are against garbage and sign errors, not bf16 noise
-    assert len(low) <= 0.15 * len(cosines), low
-    assert sorted(cosines)[len(cosines) // 2] > 0.95, sorted(cosines)[:10]
+        rel.append((float((g16 - g32).norm() / g32.norm()), n))
+    rel.sort()
+    print("bf16 vs fp32 gradient rel-L2: median %.3g, p90 %.3g, max %.3g (%s)" % (
+        rel[len(rel) // 2][0], rel[int(0.9 * len(rel))][0], rel[-1][0], rel[-1][1]))
+    assert rel[len(rel) // 2][0] <= 6e-2, rel[len(rel) // 2]
+    assert rel[int(0.9 * len(rel))][0] <= 0.35, rel[int(0.9 * len(rel)):][:5]

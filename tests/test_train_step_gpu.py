@@ -58,3 +58,23 @@ def test_captured_step_replays_reproduce_eager_gradients():
             elif rn > 1e-6 and not (0.25 * rn <= gn <= 4.0 * rn):
                 bad.append((k, n, rn, gn))
     assert not bad, bad[:8]
+
+    # ---- the loss normalisers must follow the batch, not the captured one (they are fed through a static device
+    # buffer): replay with half of the classes absent and compare with the eager losses of the same batch
+    half = synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda")
+    for t in half:
+        keep = t["labels"] % 2 == 0
+        t["labels"], t["boxes"] = t["labels"][keep], t["boxes"][keep]
+    t2 = DenseTargets.from_list(half, cfg["num_classes"], "cuda")
+    assert t2.num_boxes * 2 == targets.num_boxes
+    step._static_t.boxes.copy_(t2.boxes)
+    step._static_t.present.copy_(t2.present)
+    step._static_t.num_boxes = t2.num_boxes
+    step._static_counts.copy_(step._local_counts(step._static_t))
+    step._graph.replay()
+    got = {k: float(v) for k, v in step._static_losses.items()}
+    model.zero_grad(set_to_none=False)
+    with torch.no_grad():
+        want = {k: float(v) for k, v in step.loss(x, t2)[1].items()}
+    for k in ("bbox", "giou", "cls", "bbox_0", "giou_1"):
+        assert abs(got[k] - want[k]) <= 0.25 * abs(want[k]) + 1e-4, (k, got[k], want[k])    # dropout noise << the factor 2 of a frozen count

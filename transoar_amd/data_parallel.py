@@ -54,7 +54,7 @@ class GradientAllReducer:
         self.overlap = True          # launch a bucket's all-reduce from the autograd hook
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets, self._bucket_of, self._hooks = [], {}, []
-        self._fired, self._first_step = set(), True
+        self._fired, self._first_step, self._dead = set(), True, set()
         if not self.flat:
             return
         cur, cur_bytes = [], 0
@@ -66,9 +66,11 @@ class GradientAllReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._add_bucket(cur)
-        if self.active:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # the hooks also find, in the first step, the parameters that never receive a gradient (one rank too:
+        # with flat buckets their .grad would otherwise be a zero view and AdamW would decay them, unlike the
+        # reference where their .grad stays None)
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _add_bucket(self, params):
         b = _Bucket(list(params), params[0].device, params[0].dtype)
@@ -95,6 +97,8 @@ class GradientAllReducer:
             b.pending = b.expected
             b.handle = None
             for p, v in zip(b.params, b.views):     # someone may have replaced .grad
+                if p in self._dead:
+                    continue
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
         self._fired.clear()
@@ -104,12 +108,13 @@ class GradientAllReducer:
         if self._first_step:
             self._fired.add(p)
         b.pending -= 1
-        if b.pending == 0 and self.overlap:
+        if b.pending == 0 and self.overlap and self.active:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward, before the optimizer: wait for every bucket."""
         if not self.active:
+            self._end_first_step()
             return
         if not self.overlap:         # captured-graph step: the exchange runs after the replay
             for b in self.buckets:
@@ -119,10 +124,18 @@ class GradientAllReducer:
                 b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for b in self.buckets:
             b.handle.wait()
-        if self._first_step:
-            for b in self.buckets:
-                b.expected = sum(1 for p in b.params if p in self._fired)
-            self._first_step = False
+        self._end_first_step()
+
+    def _end_first_step(self):
+        if not (self._first_step and self.flat):
+            return
+        for b in self.buckets:
+            b.expected = sum(1 for p in b.params if p in self._fired)
+            for p in b.params:
+                if p not in self._fired:          # dead parameter: no gradient, the optimizer skips it
+                    self._dead.add(p)
+                    p.grad = None
+        self._first_step = False
 
     def remove(self):
         for h in self._hooks:

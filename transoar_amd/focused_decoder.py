@@ -31,6 +31,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import rows
+from .position_encoding import is_constant
 from .token_linear import token_linear
 
 _LEVEL_SHAPES = {
@@ -131,12 +132,13 @@ class FocusedAttn(nn.Module):
         elif rows.usable(k_pos) and k_pos.is_contiguous():
             # the positional tokens are the same tensor for every layer and (sine encoding) every step:
             # their gathered form is kept on the tensor object, keyed by its version and the index list
-            cache = getattr(k_pos, "_transoar_roi_gather", None) if not k_pos.requires_grad else None
+            const_pos = is_constant(k_pos)
+            cache = getattr(k_pos, "_transoar_roi_gather", None) if const_pos else None
             key = (k_pos._version, flat.data_ptr(), flat._version, v_tok.dtype)
             hit = None if cache is None else cache.get(key)
             if hit is None:
                 hit = (key, rows.gather(k_pos, flat).to(v_tok.dtype))
-                if not k_pos.requires_grad:
+                if const_pos:
                     if cache is None:
                         cache = k_pos._transoar_roi_gather = {}
                     if len(cache) >= 8:
@@ -237,8 +239,7 @@ class FocusedDecoderLayer(nn.Module):
         self.input_shape = torch.tensor(table[config["input_levels"]])
 
         self.register_buffer("attn_mask", self.generate_attn_masks(), persistent=False)
-        self.register_buffer("attn_bias", torch.zeros(self.attn_mask.shape).masked_fill_(
-            self.attn_mask, float("-inf")), persistent=False)
+        self._attn_bias = None       # additive form of the mask (221 MB fp32): only the dense path reads it
         roi = self._roi_lists()
         self._use_roi = roi is not None
         if roi is not None:
@@ -266,6 +267,18 @@ class FocusedDecoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
+
+    _BIAS_CACHE = {}
+
+    def _dense_bias(self):
+        """0 / -inf additive mask for the dense cross-attention, built on first use and shared by the
+        layers of a decoder (they hold equal masks)."""
+        key = (self.attn_mask.device, tuple(self.attn_mask.shape), int(self.attn_mask.sum()))
+        hit = FocusedDecoderLayer._BIAS_CACHE.get(key)
+        if hit is None or not torch.equal(hit[0], self.attn_mask):
+            bias = torch.zeros(self.attn_mask.shape, device=self.attn_mask.device).masked_fill_(self.attn_mask, float("-inf"))
+            hit = FocusedDecoderLayer._BIAS_CACHE[key] = (self.attn_mask, bias)
+        return hit[1]
 
     def generate_attn_masks(self, padding=0):
         """bool (num_queries, prod(level shape)): True = key outside the organ's
@@ -313,7 +326,7 @@ class FocusedDecoderLayer(nn.Module):
 
         q = tgt if query_pos is None else tgt + query_pos
         roi = (self.roi_index, self.roi_pad, self.roi_inv_ptr, self.roi_inv_idx) if self._use_roi else None
-        ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self.attn_bias,
+        ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self._dense_bias(),
                                       need_weights=need_weights, roi=roi, k_pos=src_pos)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
@@ -360,13 +373,14 @@ class FocusedDecoder(nn.Module):
         -> (layers, N, Q, C)"""
         assert query_embed is not None
         src = src.flatten(2).transpose(1, 2)            # a free view when src is channels-last
-        if pos.requires_grad:
+        if not is_constant(pos):                        # learned encoding: changes with training, never cached
             pos = pos.flatten(2).transpose(1, 2)
         else:                                           # sine encoding: input independent, cache its token form
             key = (tuple(pos.shape), pos.device)
             hit = self._pos_tokens.get(key)
             if hit is None:
                 hit = self._pos_tokens[key] = pos.flatten(2).transpose(1, 2).contiguous()
+                hit._transoar_constant = True
             pos = hit
         n, _, c = src.shape
         query_pos, tgt = query_embed.split(c, dim=1)

@@ -57,7 +57,14 @@ class PositionEmbeddingSine3D(nn.Module):
             with torch.no_grad():
                 pos = self._build(*src.shape[2:], device=src.device)
             self._cache[key] = pos
-        return pos[None].expand(src.shape[0], -1, -1, -1, -1)
+        out = pos[None].expand(src.shape[0], -1, -1, -1, -1)
+        out._transoar_constant = True      # input independent: consumers may cache derived forms (a learned
+        return out                         # encoding never carries this mark, whatever its requires_grad)
+
+
+def is_constant(pos):
+    """True for tensors produced by PositionEmbeddingSine3D (or cached forms derived from them)."""
+    return bool(getattr(pos, "_transoar_constant", False))
 
 
 class PositionEmbeddingLearned3D(nn.Module):

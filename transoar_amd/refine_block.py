@@ -19,6 +19,7 @@ from torch import nn
 from .ms_deform_attn import MSDeformAttn
 from .token_linear import token_linear
 from . import tokens as fused_tokens
+from .position_encoding import is_constant
 
 
 class _MapToTokens(torch.autograd.Function):
@@ -184,7 +185,7 @@ class DecoderDefAttnBlock(nn.Module):
     def _fused_ok(self, tokens, pos_embeds):
         return (tokens.is_cuda and tokens.dtype == torch.bfloat16 and tokens.is_contiguous()
                 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
-                and not any(p.requires_grad for p in pos_embeds)
+                and all(is_constant(p) for p in pos_embeds)
                 and fused_tokens.usable(tokens, None, self.d_model))
 
     def _forward_fused(self, tokens, pos_embeds, shapes, spatial, starts, sizes, ref):
@@ -212,8 +213,8 @@ class DecoderDefAttnBlock(nn.Module):
     def _pos_tokens(self, pos_map, lvl):
         """(N, C, D, H, W) positional map -> (N, V, C) tokens; the sine encoding
         is input independent, so its token form is cached per level and shape."""
-        key = ("pos", lvl, tuple(pos_map.shape), pos_map.device, pos_map.requires_grad)
-        if pos_map.requires_grad:                       # learned encoding: no caching
+        key = ("pos", lvl, tuple(pos_map.shape), pos_map.device)
+        if not is_constant(pos_map):                    # learned encoding: no caching
             return pos_map.flatten(2).transpose(1, 2)
         hit = self._geometry.get(key)
         if hit is None:

@@ -39,6 +39,7 @@ class TrainStep:
         self.amp_dtype = amp_dtype
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=graph)
         self._graph = None
+        self._static_counts = None
         self._expect_total = None
         self._want_graph = graph
         self.num_classes = config["num_classes"]
@@ -78,9 +79,14 @@ class TrainStep:
         self.model.train()
         self._static_x = data.clone()
         self._static_t = DenseTargets(targets.boxes.clone(), targets.present.clone(), targets.num_boxes)
-        self._static_counts = None
-        if self.reducer.active:      # rank-summed normalisers live in a static buffer filled before each replay
-            self._static_counts = self._local_counts(self._static_t)
+        if getattr(self.criterion, "_seg_proxy", False):
+            raise RuntimeError("TrainStep.capture: the segmentation proxy loss needs seg_targets, which the captured "
+                               "step does not carry; use the eager step for use_seg_proxy_loss configs")
+        # the loss normalisers (number of boxes, number of present classes) live in a static DEVICE buffer that
+        # is refilled before every replay -- also on one GPU: a Python int would be baked into the captured
+        # graph and mis-scale every batch whose box count differs from the captured one
+        self._static_counts = self._local_counts(self._static_t)
+        if self.reducer.active:      # ... rank-summed
             self.reducer.reduce_counts(self._static_counts)
         self.reducer.overlap = False
         # warm-up AND capture on one and the same side stream: autograd's AccumulateGrad nodes remember the
@@ -134,15 +140,15 @@ class TrainStep:
             self._static_t.boxes.copy_(targets.boxes)
             self._static_t.present.copy_(targets.present)
             self._static_t.num_boxes = targets.num_boxes
+        self._static_counts.copy_(self._local_counts(self._static_t))
         if self.reducer.active:
-            self._static_counts.copy_(self._local_counts(self._static_t))
             self.reducer.reduce_counts(self._static_counts)
         self._graph.replay()
         if self._expect_total is not None:
             expect, self._expect_total = self._expect_total, None
             got = float(self._static_total)
             if not (got == got and abs(got - expect) <= 0.2 * abs(expect) + 1e-3):
-                self._graph = None
+                self.drop_graph()
                 raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
         if self.reducer.active:
             for b in self.reducer.buckets:
@@ -150,8 +156,20 @@ class TrainStep:
                                                         group=self.reducer.group, async_op=True)
             for b in self.reducer.buckets:
                 b.handle.wait()
+        self._clip()
         self.optimizer.step()
         return self._static_total, self._static_losses
+
+    def drop_graph(self):
+        """Back to the eager step (with its overlapped gradient exchange)."""
+        self._graph = None
+        self._static_counts = None
+        self.reducer.overlap = True
+
+    def _clip(self):
+        max_norm = self.config.get("clip_max_norm", -1)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None], max_norm)
 
     def __call__(self, data, targets, seg_targets=None):
         if self._graph is not None:
@@ -163,8 +181,6 @@ class TrainStep:
         total, losses = self.loss(data, targets, seg_targets)
         total.backward()
         self.reducer.finish()
-        max_norm = self.config.get("clip_max_norm", -1)
-        if max_norm > 0:
-            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None], max_norm)
+        self._clip()
         self.optimizer.step()
         return total.detach(), losses
