@@ -2,7 +2,7 @@
 """Headline benchmark: training-step CT volumes/s of the Focused-Decoder model
 on synthetic 160x160x256 volumes (BASELINE.json metric), 1..8 MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -18,8 +18,12 @@ Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
                 region: algorithmic bytes / its average launch
                 duration measured with HIP events on the launch stream
   msda_kernels  the same for every MSDeformAttn kernel
-  cpu_baseline  one training step of the same model on the host CPU cores with
-                the oracle's torch core (kind "port"), batch 1, fp32
+  msda_backward the backward chain of the operator against SURVEY's B_bwd
+  step_ms       median / p10 / p90 of the per-step hipEvent times
+  cpu_baseline  bounded sample timed in this run: the hot operator (MSDeformAttn fwd+bwd) of the
+                use_cuda=False path on the host cores, oracle torch core (kind "port")
+  cpu_step      the WHOLE use_cuda=False training step on all host cores, measured separately
+                (--cpu-baseline-only --cpu-baseline-step, minutes per iteration) and quoted from profiles/
 """
 import argparse
 import json
@@ -46,26 +50,20 @@ if os.path.isdir(_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc, fine=None):
-    """Bytes one launch must move if every tensor is touched once."""
+def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
+    """bytes one call must move if every tensor is touched once.  Only the forward gather and the
+    backward as a whole have an algorithmic figure; the backward's internal kernels (point sort, walks) move
+    workspace bytes of this build's own making, which are not roofline credit."""
     value, out = e * N * S * M * C, e * N * Lq * M * C
     loc_attn = e_loc * N * Lq * M * L * P * 4
-    points = N * Lq * M * L * P
-    recs = points * (32 + 4)                                  # sorted 8-weight record + grad_out row index
-    fine = L if fine is None else fine                        # levels accumulated per brick in LDS (the rest: chunked walk)
     return {
-        "fwd": value + out + loc_attn,                       # SURVEY 8d B_fwd
-        "bwd_query": value + out + 2 * loc_attn + 4 * points,    # value, grad_out in; grad_loc/attn + ranks out
-        "pull": out + value + loc_attn,                      # fallback: grad_out in, grad_value out, point geometry
-        # fine levels: every sorted point + its grad_out row once, grad_value rows out.  The figure is
-        # for the whole pyramid (the coarse levels' share of points is in value_cells), split by level:
-        "value_tile": (recs + out) * fine // L + value,
-        "value_cells": (recs + out) * (L - fine) // L,
-        "cell_count": loc_attn, "cell_fill": loc_attn + recs, "scan": 0,
-    }.get(kind, 0)
+        "fwd": value + out + loc_attn,                                   # B_fwd
+        "bwd": value + out + 2 * value + 2 * loc_attn,                   # B_bwd: value, grad_out in; grad_value zero +
+    }.get(kind, 0)                                                       # accumulate; loc/attn in, their grads out
 
 
-PMC_FILE = "r01_msda_pmc_v3.json"
+BWD_KINDS = ("bwd_query", "cell_count", "scan", "cell_fill", "pull", "value_tile", "value_cells", "bwd_generic")
+PMC_FILE = "r02_msda_pmc.json"
 
 
 def pmc_traffic(kind, dims):
@@ -77,9 +75,12 @@ def pmc_traffic(kind, dims):
         sh = pmc["shape"]
         same = all(sh[k] == dims[k] for k in ("N", "S", "M", "C", "L", "Lq", "P")) and \
             sh["value_dtype"] == ("bf16" if dims["e"] == 2 else "f32")
-        name = {"fwd": "fwd_brick", "bwd_query": "bwd_query_brick", "value_tile": "bwd_value_tile",
-                "value_cells": "bwd_value_cells", "cell_fill": "cell_fill_w8"}[kind]
-        return round(pmc["kernels"][name]["hbm_bytes_per_launch"] / 1e6, 1) if same else None
+        if not same:
+            return None
+        if kind == "bwd":       # the whole chain
+            names = [k for k in pmc["kernels"] if k.startswith("bwd_") or k in ("cell_fill_w8", "scan_tiles", "coarse_rows_store")]
+            return round(sum(pmc["kernels"][k].get("hbm_bytes_per_launch", 0.0) for k in names) / 1e6, 1)
+        return round(pmc["kernels"]["fwd_mma"]["hbm_bytes_per_launch"] / 1e6, 1)
     except Exception:
         return None
 
@@ -111,11 +112,71 @@ def cpu_baseline_leg():
                                 "training step is not in this figure" % (threads, cores, t_fwd, dt)}))
 
 
+def cpu_step_leg():
+    """The model's use_cuda=False path as a whole (SURVEY 8d protocol): TransoarNet with the oracle's torch
+    restatement of ms_deform_attn_core_pytorch injected, fp32, batch 1 at the flagship geometry, refine on,
+    every host core; 1 warm + 3 timed iterations, median; forward-only and the full training step.  Minutes per
+    iteration: run separately (python bench.py --cpu-baseline-only --cpu-baseline-step), the result is kept in
+    profiles/r02_cpu_step.json and quoted by the default run as `cpu_step`."""
+    import torch
+    from oracle.torch_ref import msda3d_core_torch
+    from transoar_amd import ms_deform_attn
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.train_step import TrainStep
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    ms_deform_attn.register_debug_core(msda3d_core_torch)
+    cfg = visceral_config(refine=True, use_cuda=False)
+    cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+    torch.manual_seed(0)
+    model = TransoarNet(cfg)
+    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.float32)
+    x = torch.rand(1, 1, *cfg["volume_shape"], generator=torch.Generator().manual_seed(1234))
+    targets = synthetic_targets(1, cfg["num_classes"], seed=1)
+    timed = int(os.environ.get("TRANSOAR_CPU_STEP_ITERS", "3"))
+
+    def median_of(fn):
+        fn()                                    # 1 warm
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], ts
+
+    model.train()
+    def fwd_only():
+        with torch.no_grad():
+            step.loss(x, targets)
+    t_fwd, all_fwd = median_of(fwd_only)
+    t_step, all_step = median_of(lambda: step(x, targets))
+    rec = {"value": round(1.0 / t_step, 5), "unit": "volumes/s", "cores": cores, "kind": "port",
+           "forward_only_volumes_per_s": round(1.0 / t_fwd, 5), "step_s": [round(t, 2) for t in all_step],
+           "forward_s": [round(t, 2) for t in all_fwd],
+           "sample": "whole training step (fwd + criterion + bwd + AdamW) of the flagship model, use_cuda=False with the "
+                     "oracle torch core, fp32, batch 1, refine on, torch.set_num_threads(%d); 1 warm + %d timed, median" % (cores, timed)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_cpu_step.json"), "w"), indent=1)
+    print(json.dumps(rec))
+
+
+def cpu_step_record():
+    """The committed whole-step CPU measurement (profiles/r02_cpu_step.json), quoted with its provenance."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_step.json")))
+        rec["provenance"] = "measured separately on an MI355X box's host by `bench.py --cpu-baseline-only --cpu-baseline-step`, " \
+                            "profiles/r02_cpu_step.json; NOT re-measured in this run (minutes per iteration)"
+        return rec
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--graph", action="store_true",
@@ -127,10 +188,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager step also on one GPU")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--cpu-baseline-step", action="store_true",
+                    help="with --cpu-baseline-only: time the WHOLE use_cuda=False training step of the model on all host "
+                         "cores (1 warm + 3 timed, forward-only and full step; minutes per step) instead of the bounded "
+                         "operator sample; writes profiles/r02_cpu_step.json")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        return cpu_baseline_leg()
+        return cpu_step_leg() if args.cpu_baseline_step else cpu_baseline_leg()
 
     import torch
     import torch.distributed as dist
@@ -216,10 +281,13 @@ def main():
         _native.profile_read()
     t0 = time.perf_counter()
     host_s = 0.0
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # hipEvents on the compute stream
+    marks[0].record()
+    for i in range(args.steps):
         h0 = time.perf_counter()
         total, _ = step(x, targets)
         host_s += time.perf_counter() - h0          # time the host needs to ENQUEUE a step (no sync)
+        marks[i + 1].record()
         if os.environ.get("TRANSOAR_BENCH_TRACE"):
             if os.environ.get("TRANSOAR_BENCH_GC"):
                 import gc
@@ -227,6 +295,7 @@ def main():
             trace("timed step loss %.4f" % float(total))
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     trace("timed region done")
     # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the
     # launch stream.  A replayed graph re-records nothing, so in graph mode they come from eager steps of
@@ -258,29 +327,29 @@ def main():
         # MSDeformAttn problem of the refine block at this geometry
         shapes = [(40, 40, 64), (20, 20, 32), (10, 10, 16), (5, 5, 8)]
         S = sum(d * h * w for d, h, w in shapes)
-        fine = sum(1 for d, h, w in shapes if S * 4 < 32 * d * h * w)      # the dispatch rule of msda3d.hip (kCoarsePointsPerVoxel)
-        dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4, fine=fine)
+        dims = dict(N=args.batch, S=S, M=6, C=64, L=4, Lq=S, P=4, e=4 if args.fp32 else 2, e_loc=4)
         kernels = {}
         for kind, (ms, n) in prof.items():
-            if n == 0:
-                continue
-            avg = ms / n
-            b = msda_algorithmic_bytes(kind, **dims)
-            kernels[kind] = {"launches_per_step": n / prof_steps, "avg_ms": round(avg, 4),
-                             "algorithmic_MB": round(b / 1e6, 1),
-                             "achieved_GBps": round(b / avg / 1e6, 1) if b else None}
-        roofline = None
-        if kernels:
-            dom = max((k for k in kernels if kernels[k]["achieved_GBps"]),
-                      key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
-            kd = kernels[dom]
-            roofline = {"kernel": "msda3d_" + dom, "bound": "hbm", "achieved": kd["achieved_GBps"],
-                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kd["achieved_GBps"] / HBM_PEAK_GBPS, 4),
-                        "traffic": pmc_traffic(dom, dims), "traffic_unit": "MB per launch (PMC, profiles/%s)" % PMC_FILE,
-                        "avg_launch_ms": kd["avg_ms"], "algorithmic_MB": kd["algorithmic_MB"],
-                        "timing": "hipEvent pairs on the launch stream, " + (
-                            "timed steps" if step_mode == "eager" or step_mode.startswith("eager") else
-                            "3 eager steps right after the timed graph replays")}
+            if n:
+                kernels[kind] = {"launches_per_step": n / prof_steps, "avg_ms": round(ms / n, 4)}
+        timing = "hipEvent pairs on the launch stream, " + (
+            "timed steps" if step_mode.startswith("eager") else "3 eager steps right after the timed graph replays")
+        roofline = msda_bwd = None
+        if "fwd" in kernels:                    # the MSDeformAttn forward gather: the kernel north_star names
+            b = msda_algorithmic_bytes("fwd", **dims)
+            gbps = b / kernels["fwd"]["avg_ms"] / 1e6
+            roofline = {"kernel": "msda3d_fwd_mma", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("fwd", dims),
+                        "traffic_unit": "MB per launch (PMC, profiles/%s)" % PMC_FILE,
+                        "avg_launch_ms": kernels["fwd"]["avg_ms"], "algorithmic_MB": round(b / 1e6, 1), "timing": timing}
+        chain = [k for k in BWD_KINDS if k in kernels]
+        if chain:                               # one backward call = the chain of these kernels, against B_bwd
+            calls = kernels["bwd_query"]["launches_per_step"] if "bwd_query" in kernels else kernels[chain[0]]["launches_per_step"]
+            ms_call = sum(kernels[k]["avg_ms"] * kernels[k]["launches_per_step"] for k in chain) / calls
+            b = msda_algorithmic_bytes("bwd", **dims)
+            msda_bwd = {"kernels": chain, "ms_per_call": round(ms_call, 4), "algorithmic_MB": round(b / 1e6, 1),
+                        "achieved_GBps": round(b / ms_call / 1e6, 1), "frac": round(b / ms_call / 1e6 / HBM_PEAK_GBPS, 4),
+                        "traffic": pmc_traffic("bwd", dims), "traffic_unit": "MB per call (PMC, profiles/%s)" % PMC_FILE}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -296,6 +365,9 @@ def main():
             "value": round(global_batch * args.steps / elapsed, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "p10": round(step_ms[int(0.1 * (len(step_ms) - 1))], 3),
+                        "p90": round(step_ms[int(0.9 * (len(step_ms) - 1))], 3),
+                        "timing": "hipEvent per step on the compute stream (this rank)"},
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Focused Decoder, 160x160x256 (VISCERAL geometry), "
                                    "batch 2 per GPU, bf16 autocast, refine %s" % ("off" if args.no_refine else
@@ -305,7 +377,8 @@ def main():
                        "step_mode": step_mode,
                        "params": sum(p.numel() for p in model.parameters())},
             "loss": round(loss_value, 5), "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
-            "roofline": roofline, "msda_kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "msda_backward": msda_bwd, "msda_kernels": kernels, "cpu_baseline": cpu,
+            "cpu_step": cpu_step_record(),
         })
     else:
         line = None

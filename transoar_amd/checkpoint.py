@@ -1,0 +1,88 @@
+"""Configuration and checkpoint compatibility with the reference.
+
+* ``load_config`` -- what transoar/utils/io.py:20-38 does: ``yaml.safe_load`` of an experiment file
+  (config/attn_fpn_foc_dec_<dataset>.yaml) and, when it names a ``dataset``, a merge of that dataset's
+  ``data_info.json`` (written by the reference's preprocessing, data/preprocessor_*.py:87-93: the
+  ``bbox_properties`` the Focused Decoder builds its masks, anchors and restrictions from, plus
+  statistics).  The reference finds both relative to the working directory; here the directories are
+  arguments.  The dataset-level YAML (config/<dataset>.yaml: ``num_classes``, ``labels`` ...) is only read by
+  the reference's preprocessing, whose output already carries those keys; it can be merged explicitly.
+* ``save_checkpoint`` / ``load_checkpoint`` -- the dict of trainer.py:230-241 (``epoch``,
+  ``metric_max_val``, ``model_state_dict``, ``optimizer_state_dict``, ``scheduler_state_dict``) and the
+  resume logic of scripts/train.py:68-80 (the scheduler's ``step_size`` is overridden by the config's
+  ``lr_drop``).  Parameter names and shapes of this package's modules equal the reference's (golden fixtures
+  g4-g7), so a reference-trained ``model_state_dict`` loads with ``strict=True``.
+* ``build_scheduler`` -- scripts/train.py:65: ``StepLR(optimizer, lr_drop)``, stepped once per epoch
+  (trainer.py:220).
+"""
+import json
+import os
+
+import torch
+import yaml
+
+CHECKPOINT_KEYS = ("epoch", "metric_max_val", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict")
+
+
+def _read_yaml(path):
+    with open(path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def load_config(name_or_path, config_dir="config", dataset_root="dataset", data_info=None, dataset_yaml=None):
+    """-> dict with the reference's keys.
+
+    name_or_path  experiment name (``attn_fpn_foc_dec_visceral``: read from config_dir/<name>.yaml) or a path
+    data_info     dict, or path of a data_info.json; default dataset_root/<config['dataset']>/data_info.json
+                  (io.py:33-36).  Raises FileNotFoundError when the config names a dataset and none is found:
+                  the model cannot be built without ``bbox_properties``.
+    dataset_yaml  optional config/<dataset>.yaml (num_classes, labels ...) merged first, for data_info files
+                  that do not repeat those keys.
+    """
+    path = name_or_path if os.path.isfile(str(name_or_path)) else os.path.join(config_dir, str(name_or_path) + ".yaml")
+    config = _read_yaml(path)
+    if dataset_yaml is not None:
+        config.update(_read_yaml(dataset_yaml))
+    if "dataset" in config or data_info is not None:
+        if data_info is None:
+            data_info = os.path.join(dataset_root, config["dataset"], "data_info.json")
+        if not isinstance(data_info, dict):
+            with open(data_info, "r") as f:
+                data_info = json.load(f)
+        config.update(data_info)
+    if "bbox_properties" in config:      # JSON object keys are strings; the model indexes classes by str(c)
+        config["bbox_properties"] = {str(k): v for k, v in config["bbox_properties"].items()}
+    return config
+
+
+def build_scheduler(optimizer, config):
+    return torch.optim.lr_scheduler.StepLR(optimizer, int(config["lr_drop"]))
+
+
+def save_checkpoint(path, model, optimizer, scheduler, epoch, metric_max_val=0.0):
+    torch.save({
+        "epoch": epoch,
+        "metric_max_val": metric_max_val,
+        "model_state_dict": model.state_dict(),
+        "optimizer_state_dict": optimizer.state_dict(),
+        "scheduler_state_dict": scheduler.state_dict(),
+    }, path)
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None, config=None, strict=True, map_location="cpu"):
+    """Load a checkpoint written by the reference's Trainer (or by save_checkpoint).  -> (epoch, metric_max_val).
+    Optimizer / scheduler states are restored when the objects are given; with ``config`` the scheduler's
+    step size follows ``lr_drop`` as in scripts/train.py:70."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    missing = [k for k in ("model_state_dict",) if k not in ckpt]
+    if missing:
+        raise KeyError("%s is not a transoar checkpoint: no %s" % (path, missing))
+    model.load_state_dict(ckpt["model_state_dict"], strict=strict)
+    if optimizer is not None and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    if scheduler is not None and "scheduler_state_dict" in ckpt:
+        state = dict(ckpt["scheduler_state_dict"])
+        if config is not None:
+            state["step_size"] = int(config["lr_drop"])
+        scheduler.load_state_dict(state)
+    return ckpt.get("epoch", 0), ckpt.get("metric_max_val", 0)

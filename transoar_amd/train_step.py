@@ -4,7 +4,7 @@ backward (with the data-parallel gradient exchange overlapped), AdamW.
 The unit the headline metric times.  Follows the step of
 transoar/trainer.py:54-92 and the optimiser set-up of scripts/train.py:52-65
 (two parameter groups: ``_backbone`` at lr_backbone, the rest at lr; AdamW,
-weight decay 1e-4; optional gradient clipping), with these deliberate changes:
+weight decay 1e-4; optional gradient clipping, StepLR(lr_drop) stepped per epoch through end_epoch()), with these deliberate changes:
   * bf16 autocast without a GradScaler (the reference uses fp16 + GradScaler on
     CUDA; bf16 needs no loss scaling) -- fp32 master weights either way;
   * no ``.item()`` in the step (the reference does six host syncs per step,
@@ -33,9 +33,12 @@ def build_optimizer(model, config, fused=None):
 
 class TrainStep:
     def __init__(self, model, criterion, config, optimizer=None, amp_dtype=torch.bfloat16,
-                 process_group=None, bucket_bytes=48 << 20, graph=False):
+                 process_group=None, bucket_bytes=48 << 20, graph=False, scheduler=None):
         self.model, self.criterion, self.config = model, criterion, config
         self.optimizer = optimizer or build_optimizer(model, config)
+        # scripts/train.py:65: StepLR(optim, lr_drop), stepped once per EPOCH (trainer.py:220) -> end_epoch()
+        self.scheduler = scheduler if scheduler is not None or "lr_drop" not in config else \
+            torch.optim.lr_scheduler.StepLR(self.optimizer, int(config["lr_drop"]))
         self.amp_dtype = amp_dtype
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=graph)
         self._graph = None
@@ -44,6 +47,12 @@ class TrainStep:
         self._want_graph = graph
         self.num_classes = config["num_classes"]
         self.device_type = next(model.parameters()).device.type
+
+    def end_epoch(self):
+        """Advance the learning-rate schedule (the reference steps it after every epoch, trainer.py:220).  The
+        fused AdamW reads the group's lr on every step, so this is safe next to a captured graph."""
+        if self.scheduler is not None:
+            self.scheduler.step()
 
     def loss(self, data, targets, seg_targets=None, counts=None):
         """-> (weighted total, dict of unweighted losses); forward only.  counts: already
