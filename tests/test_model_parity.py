@@ -195,13 +195,20 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     from transoar_amd.conv3d import Conv3dK3
     from transoar_amd.transoarnet import TransoarNet, build_criterion
     cfg = small_model_config(refine, use_cuda=True)
+    # stock random initialisation (the closed-form weights of the golden fixtures make every query alike and the
+    # encoder gradients vanish: a pathological operating point for a bf16 comparison); the heads start at zero
+    # in the reference (no gradient would reach the body): un-zero them
+    torch.manual_seed(0)
     net = TransoarNet(cfg)
-    fill_deterministic(net)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1 and float(p.abs().max()) == 0:
+                torch.nn.init.xavier_uniform_(p)
     net = net.cuda().train()
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    x = analytic_volume((160, 160, 256), batch=1).cuda()
+    x = torch.rand(1, 1, 160, 160, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     targets = synthetic_targets(1, 20, seed=1, device="cuda")
     crit = build_criterion(cfg)
     coefs = cfg["loss_coefs"]
@@ -237,18 +244,19 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     # ---- stated bf16 tolerances of the model, against the fp32 run of the same kernels' host model on the
     # same weights (which the g7 test pins to the reference at 1e-4).  bf16 carries 8 mantissa bits and every
     # activation of the 12-conv backbone + 2 refine layers + 3 decoder layers is rounded to it:
-    #   pred_boxes (values in [0,1])        max abs error   <= 5e-3      (observed 6e-4)
-    #   pred_logits                          max error       <= 0.12 of the largest |logit| + 2e-2 (observed 0.08; rms 0.02)
-    #   each of the 11 loss scalars          relative error  <= 8e-2      (observed 5e-2: matching flips, see below)
-    #   parameter gradients of a smooth functional of the outputs, relative L2: median <= 6e-2, 90 % <= 0.5
+    #   pred_boxes (values in [0,1])        max abs error   <= 5e-3      (observed 1.4e-3)
+    #   pred_logits                          max error       <= 0.1 of the largest |logit| + 2e-2 (observed 0.053; rms 0.013)
+    #   each of the 11 loss scalars          relative error  <= 1e-2      (observed 2e-3, same matches in both passes)
+    #   parameter gradients, relative L2     median <= 6e-2 (observed 0.03), 90 % <= 0.4 (observed 0.26), all <= 2.5
+    #                                        (observed 1.14 on the first InstanceNorm's bias)
     # (the first encoder convolutions sit behind 12 InstanceNorms: their gradients are ill-conditioned --
     # >10 % checksum drift between two fp32 CPU runs, tests/test_data_parallel.py -- hence the tail bound)
     o32, o16 = outs["fp32"], outs["bf16"]
     assert float((o16["pred_boxes"].float() - o32["pred_boxes"]).abs().max()) <= 5e-3
     lmax = float(o32["pred_logits"].abs().max())
-    assert float((o16["pred_logits"].float() - o32["pred_logits"]).abs().max()) <= 0.12 * lmax + 2e-2
+    assert float((o16["pred_logits"].float() - o32["pred_logits"]).abs().max()) <= 0.1 * lmax + 2e-2
     for k, v32 in loss_vals["fp32"].items():
-        assert abs(loss_vals["bf16"][k] - v32) <= 8e-2 * abs(v32) + 2e-3, (k, loss_vals["bf16"][k], v32)
+        assert abs(loss_vals["bf16"][k] - v32) <= 1e-2 * abs(v32) + 1e-3, (k, loss_vals["bf16"][k], v32)
     rel = []
     for n, g32 in grads["fp32"].items():
         g16 = grads["bf16"][n]
@@ -259,4 +267,5 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     print("bf16 vs fp32 gradient rel-L2: median %.3g, p90 %.3g, max %.3g (%s)" % (
         rel[len(rel) // 2][0], rel[int(0.9 * len(rel))][0], rel[-1][0], rel[-1][1]))
     assert rel[len(rel) // 2][0] <= 6e-2, rel[len(rel) // 2]
-    assert rel[int(0.9 * len(rel))][0] <= 0.5, rel[int(0.9 * len(rel)):][:5]
+    assert rel[int(0.9 * len(rel))][0] <= 0.4, rel[int(0.9 * len(rel)):][:5]
+    assert rel[-1][0] <= 2.5, rel[-3:]

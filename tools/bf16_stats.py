@@ -7,7 +7,12 @@ from transoar_amd.conv3d import Conv3dK3
 from transoar_amd.transoarnet import TransoarNet, build_criterion
 for refine in (False, True):
     cfg = small_model_config(refine, use_cuda=True)
-    torch.manual_seed(0); net = TransoarNet(cfg); net = net.cuda().train()
+    torch.manual_seed(0); net = TransoarNet(cfg)
+    with torch.no_grad():
+        for p_ in net.parameters():          # the heads start at zero (no gradient reaches the body): un-zero them
+            if p_.dim() > 1 and float(p_.abs().max()) == 0:
+                torch.nn.init.xavier_uniform_(p_)
+    net = net.cuda().train()
     x = torch.rand(1, 1, 160, 160, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout): m.p = 0.0

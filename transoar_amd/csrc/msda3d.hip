@@ -313,7 +313,20 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
                      d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
   bool brick_done = false;
   if constexpr (sizeof(VT) == 2) {
-    if (q_order.enabled && fold_count && d.C == 64 && d.P == 4 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
+    bool small = d.L <= kMmaLevels;
+    for (int l = 0; small && l < d.L; ++l) small = q_order.D[l] <= 1000 && q_order.H[l] <= 1000 && q_order.W[l] <= 1000;
+    if (q_order.enabled && fold_count && small && d.C == 64 && d.P == 4 &&
+        !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
+      ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+      const long n_wave = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M * 4;
+      hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
+                         v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes,
+                         n_wave, q_order);
+      brick_done = true;
+    }
+  }
+  if constexpr (sizeof(VT) == 2) {
+    if (!brick_done && q_order.enabled && fold_count && d.C == 64 && d.P == 4 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
       ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
       const long n_wg = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M;
       hipLaunchKernelGGL((msda3d_bwd_query_brick<VT, LT, 4, 64>), dim3(((n_wg + 7) / 8) * 8), dim3(kBrickThreads),

@@ -422,4 +422,340 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// grad_sampling_loc / grad_attn_weight on the matrix cores, same wave = 32 queries x 1 head structure.
+// Per (point, corner) the backward needs  dot = <grad_out[q, :], value[row, :]>  -- for the 32 queries of a wave
+// against the rows of their box that is the product  G[r, q] = V[r, c] . GO^T[c, q]  (64 channels = 4 MFMA
+// K-steps, both operands read with their channel axis contiguous: no transposes, products of 16-bit values
+// exact in fp32).  G goes through an LDS block [row][query]; every lane picks its 16 corner dots out of it
+// and finishes its two points at the end of the level.  Also does the binning pass of the grad_value point
+// sort (rank of every point inside its cell): an LDS histogram over the wave's cell box, then one returning
+// global atomic per touched cell.
+// ---------------------------------------------------------------------------
+template <typename VT, typename LT>
+__global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
+    const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
+    const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
+    int* __restrict__ bin_count, int* __restrict__ bin_rank, int cells_per_slab, int S, int M, int L,
+    unsigned value_bytes, long n_units, BrickOrder order) {
+  constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
+  __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
+  __shared__ __attribute__((aligned(16))) float gbuf[WR * 32];      // G block [row][query] (+ a zero spare row); the cell histogram before that
+
+  const long u = xcd_contiguous_block(blockIdx.x, n_units);
+  if (u < 0) return;
+  const int lane = threadIdx.x;
+  const int j = lane & 31, kg = lane >> 5;
+  const int sb = static_cast<int>(u & 3);
+  const long t1 = u >> 2;
+  const int m = static_cast<int>(t1 % M);
+  const long t2 = t1 / M;
+  const int bricks = order.pad_start[order.L] >> 7;
+  const int brick = bricks - 1 - static_cast<int>(t2 % bricks);
+  const long b = t2 / bricks;
+  const int slot = (2 * (sb >> 1) + (j >> 4)) * 32 + ((j >> 2) & 3) * 8 + 4 * (sb & 1) + (j & 3);
+  const int s = brick_slot_to_row(order, brick * kBrickSlots + slot);
+  const bool live = s >= 0;
+  const long item = live ? (b * S + s) * M + m : 0;
+  const int LP = L * P;
+  const unsigned row_bytes = static_cast<unsigned>(M) * C * sizeof(VT);
+  const unsigned head_off = static_cast<unsigned>((b * S * M + m) * C * sizeof(VT));
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<VT*>(value), 0, static_cast<int>(value_bytes), 0x00020000);
+
+  // B operand for the whole kernel: grad_out[q = j][16 s + 8 kg .. + 7], s = 0..3, packed as stored
+  s16x8 gof[4];
+#pragma unroll
+  for (int sk = 0; sk < 4; ++sk) {
+    u32x4 raw{0u, 0u, 0u, 0u};
+    if (live) raw = *reinterpret_cast<const u32x4*>(grad_out + item * C + 16 * sk + 8 * kg);
+    gof[sk] = __builtin_bit_cast(s16x8, raw);
+  }
+
+  MmaPoint pt[kMmaLevels][2];
+  MmaBox box[kMmaLevels];
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    box[l] = MmaBox{0, 0, 0, 0, 0, 0};
+    if (l >= L) return;
+    const int D = order.D[l], H = order.H[l], W = order.W[l];
+    int lo_d = 32767, lo_h = 32767, lo_w = 32767, hi_d = -1, hi_h = -1, hi_w = -1;
+    float lx[2] = {0.f, 0.f}, ly[2] = {0.f, 0.f}, lz[2] = {0.f, 0.f}, la[2] = {0.f, 0.f};
+    if (live) {
+      const long jx = item * LP + l * P + 2 * kg;
+      if constexpr (sizeof(LT) == 4) {
+        const float2 q0 = *reinterpret_cast<const float2*>(loc + 3 * jx), q1 = *reinterpret_cast<const float2*>(loc + 3 * jx + 2),
+                     q2 = *reinterpret_cast<const float2*>(loc + 3 * jx + 4), qa = *reinterpret_cast<const float2*>(attn + jx);
+        lx[0] = q0.x; ly[0] = q0.y; lz[0] = q1.x; lx[1] = q1.y; ly[1] = q2.x; lz[1] = q2.y;
+        la[0] = qa.x; la[1] = qa.y;
+      } else {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          lx[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi)));
+          ly[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 1));
+          lz[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 2));
+          la[pi] = static_cast<float>(Elem<LT>::ld(attn + jx + pi));
+        }
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      MmaPoint g{0x3fffffff, 0.f, 0.f, 0.f, 0.f};
+      const float w_im = pixel_coord(lx[pi], W), h_im = pixel_coord(ly[pi], H), d_im = pixel_coord(lz[pi], D);
+      if (live && d_im > -1.f && h_im > -1.f && w_im > -1.f && d_im < D && h_im < H && w_im < W) {
+        const float fd = floorf(d_im), fh = floorf(h_im), fw = floorf(w_im);
+        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
+        g.dhw = (d0 + 1) | ((h0 + 1) << 10) | ((w0 + 1) << 20);
+        g.ld = d_im - fd; g.lh = h_im - fh; g.lw = w_im - fw; g.a = la[pi];
+        lo_d = min(lo_d, max(d0, 0)); hi_d = max(hi_d, min(d0 + 1, D - 1));
+        lo_h = min(lo_h, max(h0, 0)); hi_h = max(hi_h, min(h0 + 1, H - 1));
+        lo_w = min(lo_w, max(w0, 0)); hi_w = max(hi_w, min(w0 + 1, W - 1));
+      }
+      pt[l][pi] = g;
+    }
+    const int r0 = wave_min_pk16(pack16(lo_d, lo_h)), r1 = wave_min_pk16(pack16(lo_w, -hi_d)), r2 = wave_min_pk16(pack16(-hi_h, -hi_w));
+    hi_d = -(r1 >> 16);
+    if (hi_d < 0) return;
+    lo_d = static_cast<short>(r0); lo_h = r0 >> 16; lo_w = static_cast<short>(r1);
+    hi_h = -static_cast<int>(static_cast<short>(r2)); hi_w = -(r2 >> 16);
+    box[l] = MmaBox{lo_d, lo_h, lo_w, hi_d - lo_d + 1, hi_h - lo_h + 1, hi_w - lo_w + 1};
+  });
+
+  for (int i = lane; i < WR * 32 / 4; i += 64) reinterpret_cast<float4*>(gbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < KB * VP / 16; i += 64) reinterpret_cast<float4*>(vbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
+
+  const int st_row = lane >> 3, st_vec = lane & 7;
+  auto load_block = [&](auto lc, int kb, u32x4 (&pre)[8]) {
+    constexpr int l = decltype(lc)::value;
+    const MmaBox bx = box[l];
+    const int H = order.H[l], W = order.W[l], start = order.start[l];
+    const int THW = bx.TH * bx.TW, R = bx.TD * THW;
+    const float inv_thw = __builtin_amdgcn_rcpf(static_cast<float>(THW)), inv_tw = __builtin_amdgcn_rcpf(static_cast<float>(bx.TW));
+    const int r = kb * KB + lane;
+    const int rd = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_thw), rr = r - __mul24(rd, THW);
+    const int rh = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_tw), rw = rr - __mul24(rh, bx.TW);
+    const int grow = start + __mul24(__mul24(bx.bd + rd, H) + (bx.bh + rh), W) + (bx.bw + rw);
+    const unsigned past = static_cast<unsigned>((R - 1 - r) >> 31);
+    const int row_off = static_cast<int>((head_off + __umul24(static_cast<unsigned>(grow), row_bytes)) | (past & 0xfffffff0u));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned off = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute((it * 8 + st_row) * 4, row_off)) + st_vec * 16u;
+      pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+  };
+
+  u32x4 pre[8];
+  bool have_pre = false;
+  int cell_start = 0;
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if (l >= L) return;
+    const int D = order.D[l], H = order.H[l], W = order.W[l];
+    const int level_cells = (D + 1) * (H + 1) * (W + 1);
+    const int my_cell_start = cell_start;
+    cell_start += level_cells;
+    const long jx = item * LP + l * P + 2 * kg;
+    if (box[l].TD == 0) {                        // no valid point of the wave: zero gradients, no ranks
+      if (live) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          if (bin_count != nullptr) bin_rank[jx + pi] = -1;
+          Elem<LT>::st(grad_attn + jx + pi, 0.f);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Elem<LT>::st(grad_loc + 3 * (jx + pi) + k, 0.f);
+        }
+      }
+      return;
+    }
+    const MmaBox bx = box[l];
+    const int THW = bx.TH * bx.TW, R = bx.TD * THW;
+
+    // ---- binning pass of the point sort
+    if (bin_count != nullptr) {
+      int* slab_count = bin_count + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
+      int* hist = reinterpret_cast<int*>(gbuf);
+      const int CH = bx.TH + 1, CW = bx.TW + 1;
+      const int ncells = (bx.TD + 1) * CH * CW;
+      const bool use_hist = ncells <= KB * 32;                 // the spare row above stays zero
+      int rank[2] = {-1, -1}, lcell[2] = {0, 0};
+      if (use_hist) {
+        for (int c = lane; c < ncells; c += 64) hist[c] = 0;
+      }
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int dhw = pt[l][pi].dhw;
+        if (dhw == 0x3fffffff) continue;
+        const int c1d = dhw & 1023, c1h = (dhw >> 10) & 1023, c1w = (dhw >> 20) & 1023;      // d0+1, h0+1, w0+1
+        if (use_hist) {
+          lcell[pi] = ((c1d - bx.bd) * CH + (c1h - bx.bh)) * CW + (c1w - bx.bw);
+          rank[pi] = atomicAdd(&hist[lcell[pi]], 1);
+        } else {
+          rank[pi] = atomicAdd(slab_count + (c1d * (H + 1) + c1h) * (W + 1) + c1w, 1);
+        }
+      }
+      if (use_hist) {
+        const float inv_chw = __builtin_amdgcn_rcpf(static_cast<float>(CH * CW)), inv_cw = __builtin_amdgcn_rcpf(static_cast<float>(CW));
+        for (int c = lane; c < ncells; c += 64) {
+          const int n = hist[c];
+          if (n > 0) {
+            const int cd = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_chw), cr = c - cd * (CH * CW);
+            const int ch = static_cast<int>((static_cast<float>(cr) + 0.5f) * inv_cw), cw = cr - ch * CW;
+            hist[c] = atomicAdd(slab_count + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
+          }
+        }
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+          if (rank[pi] >= 0) rank[pi] += hist[lcell[pi]];
+        // the histogram lived in the G block: its spare row was not touched, the rest is rewritten before use
+      }
+      if (live) {
+        bin_rank[jx] = rank[0];
+        bin_rank[jx + 1] = rank[1];
+      }
+    }
+
+    // ---- this lane's 16 corner slots: word offset in a G block that would hold the whole box
+    int ecol[16];
+    float dots[16];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const MmaPoint g = pt[l][pi];
+      const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
+      const bool okp = g.dhw != 0x3fffffff;
+      const int cb = (__mul24(__mul24(d0 - bx.bd, bx.TH) + (h0 - bx.bh), bx.TW) + (w0 - bx.bw)) * 32 + j;
+      const bool vd[2] = {okp && static_cast<unsigned>(d0) < static_cast<unsigned>(D), okp && static_cast<unsigned>(d0 + 1) < static_cast<unsigned>(D)};
+      const bool vh[2] = {static_cast<unsigned>(h0) < static_cast<unsigned>(H), static_cast<unsigned>(h0 + 1) < static_cast<unsigned>(H)};
+      const bool vw[2] = {static_cast<unsigned>(w0) < static_cast<unsigned>(W), static_cast<unsigned>(w0 + 1) < static_cast<unsigned>(W)};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = c >> 1, dh = c & 1;
+        const int col = cb + (dd ? THW * 32 : 0) + (dh ? bx.TW * 32 : 0);
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          ecol[pi * 8 + 2 * c + dw] = (vd[dd] && vh[dh] && vw[dw]) ? col + 32 * dw : -64;
+          dots[pi * 8 + 2 * c + dw] = 0.f;
+        }
+      }
+    }
+
+    if (R > kMmaDenseRows) {
+      // ---- non-local level: corner by corner from global memory.  Both lanes of a query work on the same
+      // point (each on its 32 of the 64 channels: those of its grad_out fragments), halves meet by a lane swap.
+#pragma unroll 1
+      for (int p4 = 0; p4 < 4; ++p4) {
+        MmaPoint g = (p4 & 1) ? pt[l][1] : pt[l][0];
+        MmaPoint o;
+        o.dhw = __shfl_xor(g.dhw, 32, 64);
+        const bool mine = (p4 >> 1) == kg;
+        const int dhw = mine ? g.dhw : o.dhw;
+        float part[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part[k] = 0.f;
+        if (dhw != 0x3fffffff) {
+          const int d0 = (dhw & 1023) - 1, h0 = ((dhw >> 10) & 1023) - 1, w0 = ((dhw >> 20) & 1023) - 1;
+#pragma unroll 1
+          for (int k = 0; k < 8; ++k) {
+            const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+            const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
+            float acc = 0.f;
+            if (static_cast<unsigned>(d) < static_cast<unsigned>(D) && static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
+                static_cast<unsigned>(w) < static_cast<unsigned>(W)) {
+              const long grow = order.start[l] + (static_cast<long>(d) * H + h) * W + w;
+              const VT* src = value + ((b * S + grow) * M + m) * C + 8 * kg;
+#pragma unroll
+              for (int sk = 0; sk < 4; ++sk) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src + 16 * sk);
+                const u32x4 gq = __builtin_bit_cast(u32x4, gof[sk]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = Elem<VT>::dot2(v[t], gq[t], acc);
+              }
+            }
+            // part[k] with a runtime k would index registers dynamically: select instead
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) part[kk] = kk == k ? acc : part[kk];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float full = part[k] + __shfl_xor(part[k], 32, 64);
+          // corner order of dots[]: c = dd*2 + dh, then dw  ==  k = dd*4 + dh*2 + dw
+          if (mine) {
+            if (p4 & 1) dots[8 + k] = full;
+            else dots[k] = full;
+          }
+        }
+      }
+      have_pre = false;
+    } else {
+      const int nblk = (R + KB - 1) / KB;
+      if (!have_pre) load_block(lc, 0, pre);
+      for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * KB;
+        const int rows_here = min(KB, R - k0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+        if (rows_here > 32) {
+#pragma unroll
+          for (int it = 4; it < 8; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+        }
+        have_pre = false;
+        if (kb + 1 < nblk) {
+          load_block(lc, kb + 1, pre);
+          have_pre = true;
+        } else if constexpr (l + 1 < kMmaLevels) {
+          if (l + 1 < L && box[l + 1].TD != 0) {
+            const MmaBox nb = box[l + 1];
+            if (nb.TD * nb.TH * nb.TW <= kMmaDenseRows) {
+              load_block(IntC<l + 1>{}, 0, pre);
+              have_pre = true;
+            }
+          }
+        }
+        // ---- G[row, q] for the 32-row tiles of the block, through LDS [row][query]
+        for (int tile = 0; tile * 32 < rows_here; ++tile) {
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+          const unsigned char* arow = vbuf + (tile * 32 + j) * VP + 16 * kg;
+#pragma unroll
+          for (int sk = 0; sk < 4; ++sk) {
+            const s16x8 a = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(arow + 32 * sk));
+            acc = Mma<VT>::mfma(a, gof[sk], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gbuf[(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + j] = acc[r];
+        }
+        // ---- every lane's corner dots (a corner outside this block reads the zero spare row)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          dots[e] += gbuf[min(static_cast<unsigned>(ecol[e] - k0 * 32), static_cast<unsigned>(KB * 32 + j))];
+      }
+    }
+
+    // ---- finish the two points of this lane on this level
+    if (live) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const MmaPoint g = pt[l][pi];
+        float pa = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+          const float dot = dots[pi * 8 + k];
+          const float wd = dd ? g.ld : 1.f - g.ld, wh = dh ? g.lh : 1.f - g.lh, ww = dw ? g.lw : 1.f - g.lw;
+          pa += (wd * wh * ww) * dot;
+          px += (dw ? dot : -dot) * (wd * wh);
+          py += (dh ? dot : -dot) * (wd * ww);
+          pz += (dd ? dot : -dot) * (wh * ww);
+        }
+        Elem<LT>::st(grad_attn + jx + pi, pa);
+        Elem<LT>::st(grad_loc + 3 * (jx + pi), px * g.a * static_cast<float>(W));
+        Elem<LT>::st(grad_loc + 3 * (jx + pi) + 1, py * g.a * static_cast<float>(H));
+        Elem<LT>::st(grad_loc + 3 * (jx + pi) + 2, pz * g.a * static_cast<float>(D));
+      }
+    }
+  });
+}
+
 }  // namespace transoar
