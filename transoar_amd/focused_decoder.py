@@ -207,7 +207,7 @@ class FocusedAttn(nn.Module):
         kh = self.k_proj(k).view(b, n_kv, h, hd).transpose(1, 2)
         vh = self.v_proj(v).view(b, n_kv, h, hd).transpose(1, 2)
         qh = self.k_proj(q).view(b, n_q, h, hd).transpose(1, 2)     # sic: k_proj
-        bias = mask
+        bias = mask() if callable(mask) else mask          # the dense additive mask is built lazily (221 MB)
         if self.pos_bias is not None:
             bias = self.pos_bias if bias is None else bias + self.pos_bias
         weights = None
@@ -271,14 +271,16 @@ class FocusedDecoderLayer(nn.Module):
     _BIAS_CACHE = {}
 
     def _dense_bias(self):
-        """0 / -inf additive mask for the dense cross-attention, built on first use and shared by the
-        layers of a decoder (they hold equal masks)."""
-        key = (self.attn_mask.device, tuple(self.attn_mask.shape), int(self.attn_mask.sum()))
-        hit = FocusedDecoderLayer._BIAS_CACHE.get(key)
-        if hit is None or not torch.equal(hit[0], self.attn_mask):
-            bias = torch.zeros(self.attn_mask.shape, device=self.attn_mask.device).masked_fill_(self.attn_mask, float("-inf"))
-            hit = FocusedDecoderLayer._BIAS_CACHE[key] = (self.attn_mask, bias)
-        return hit[1]
+        """0 / -inf additive mask for the dense cross-attention, built on first use (one host sync, never on
+        the RoI path) and shared by the layers of a decoder, which hold equal masks."""
+        if self._attn_bias is None or self._attn_bias.device != self.attn_mask.device:
+            key = (self.attn_mask.device, tuple(self.attn_mask.shape), int(self.attn_mask.sum()))
+            hit = FocusedDecoderLayer._BIAS_CACHE.get(key)
+            if hit is None or not torch.equal(hit[0], self.attn_mask):
+                bias = torch.zeros(self.attn_mask.shape, device=self.attn_mask.device).masked_fill_(self.attn_mask, float("-inf"))
+                hit = FocusedDecoderLayer._BIAS_CACHE[key] = (self.attn_mask, bias)
+            self._attn_bias = hit[1]
+        return self._attn_bias
 
     def generate_attn_masks(self, padding=0):
         """bool (num_queries, prod(level shape)): True = key outside the organ's
@@ -326,7 +328,7 @@ class FocusedDecoderLayer(nn.Module):
 
         q = tgt if query_pos is None else tgt + query_pos
         roi = (self.roi_index, self.roi_pad, self.roi_inv_ptr, self.roi_inv_idx) if self._use_roi else None
-        ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self._dense_bias(),
+        ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self._dense_bias,
                                       need_weights=need_weights, roi=roi, k_pos=src_pos)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
