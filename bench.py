@@ -183,6 +183,7 @@ def main():
                     help="replay forward+loss+backward as one HIP graph: the default on one GPU (about 2 ms faster per "
                          "step at K=10, host enqueue 9 ms instead of 56 ms).  With more than one rank the default is the "
                          "eager step, whose bucketed all-reduce overlaps the backward (DESIGN.md sections 6 and 8)")
+    ap.add_argument("--swin", action="store_true", help="BASELINE config #4: Swin encoder stages (use_encoder_attn=True)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager step also on one GPU")
@@ -225,7 +226,7 @@ def main():
     from transoar_amd.train_step import TrainStep
     from transoar_amd.transoarnet import TransoarNet, build_criterion
 
-    cfg = visceral_config(refine=not args.no_refine, use_cuda=True)
+    cfg = visceral_config(refine=not args.no_refine, use_cuda=True, swin=args.swin)
     cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
@@ -370,8 +371,8 @@ def main():
                         "timing": "hipEvent per step on the compute stream (this rank)"},
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Focused Decoder, 160x160x256 (VISCERAL geometry), "
-                                   "batch 2 per GPU, bf16 autocast, refine %s" % ("off" if args.no_refine else
-                                                                                     "on (use_decoder_attn, use_cuda)"),
+                                   "batch 2 per GPU, bf16 autocast, refine %s%s" % ("off" if args.no_refine else "on (use_decoder_attn, use_cuda)",
+                                                                       ", Swin encoder (configs[3])" if args.swin else ""),
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "volume": list(cfg["volume_shape"]),
                        "parallelism": "dp%d" % world, "weights": "random init", "optimizer": "AdamW fused",
                        "step_mode": step_mode,

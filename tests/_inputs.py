@@ -125,6 +125,14 @@ def small_backbone_config(refine, use_cuda=False, levels=("P2", "P3", "P4", "P5"
         n_points=4, use_cuda=use_cuda, use_seg_proxy_loss=False, fg_bg=True)
 
 
+def small_swin_config(conv_merging=False):
+    """Reduced-width backbone with the Swin encoder (use_encoder_attn=True): start_channels 6 so that the Swin
+    stage widths 12/24/48/96 divide by the heads 3/6/12/24."""
+    cfg = small_backbone_config(False)
+    cfg.update(use_encoder_attn=True, start_channels=6, conv_merging=conv_merging, drop_path_rate=0.2)
+    return cfg
+
+
 def small_model_config(refine, use_cuda=False):
     """Reduced-width VISCERAL-geometry model (the Focused Decoder's mask table
     only admits 160x160x256, focused_decoder.py:99-117)."""

@@ -16,6 +16,7 @@ no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
 
     python tests/golden/make_golden.py            # rewrites the op/module fixtures g1..g5
     python tests/golden/make_golden.py --models   # additionally g6 (backbone), g7 (whole model)
+    python tests/golden/make_golden.py --swin     # only g8 (Swin encoder backbone)
 
 g6/g7 import the reference's full model, which needs two container-only shims
 (a stub ``timm.models.layers`` and ``Tensor.cuda = identity``).
@@ -202,7 +203,7 @@ def g5_refine_block():
     np.savez_compressed(os.path.join(HERE, "g5_refine_block.npz"), **store)
 
 
-if __name__ == "__main__" and "--models" not in sys.argv:
+if __name__ == "__main__" and "--models" not in sys.argv and "--swin" not in sys.argv:
     g1_small()
     g2_edge()
     g3_medium()
@@ -295,6 +296,40 @@ def g7_whole_model():
         store[tag + ".grad_abs_sums"] = np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads])
     np.savez_compressed(os.path.join(HERE, "g7_whole_model.npz"), **store)
 
+
+def g8_swin_backbone():
+    """AttnFPN with use_encoder_attn=True (Swin stages 2-5; BASELINE config #4 at reduced width) on a 32x32x64
+    volume: window / shifted-window blocks with padding (16x16x32, 8x8x16 grids), a mixed case (4x4x8: one
+    window along D and H, shifted along W) and a single-window stage (2x2x4); both patch-merge variants."""
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import analytic_volume, fill_deterministic, small_swin_config
+    from transoar.models.backbones.attn_fpn import AttnFPN
+    x = analytic_volume((32, 32, 64))
+    store = {}
+    for tag, conv_merging in (("linear_merge", False), ("conv_merge", True)):
+        net = AttnFPN(small_swin_config(conv_merging)).eval()
+        fill_deterministic(net)
+        enc = net._encoder(x)
+        out = net(x)
+        total = sum(o.sum() for o in out.values())
+        params = dict(net.named_parameters())
+        grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+        for k, v in enc.items():
+            if k not in ("C0", "C1"):          # the convolutional stages are pinned by g6
+                store["%s.%s" % (tag, k)] = v.detach().numpy()
+        for k, v in out.items():
+            store["%s.%s" % (tag, k)] = v.detach().numpy()
+        store[tag + ".state_names"] = np.array(list(net.state_dict().keys()))
+        store[tag + ".grad_names"] = np.array(list(params.keys()))
+        store[tag + ".grad_sums"] = np.array([0.0 if g is None else g.double().sum().item() for g in grads])
+        store[tag + ".grad_abs_sums"] = np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads])
+    np.savez_compressed(os.path.join(HERE, "g8_swin_backbone.npz"), **store)
+
+
+if __name__ == "__main__" and "--swin" in sys.argv:
+    g8_swin_backbone()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--models" in sys.argv:
     g6_backbone()

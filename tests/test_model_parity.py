@@ -269,3 +269,59 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     assert rel[len(rel) // 2][0] <= 6e-2, rel[len(rel) // 2]
     assert rel[int(0.9 * len(rel))][0] <= 0.4, rel[int(0.9 * len(rel)):][:5]
     assert rel[-1][0] <= 2.5, rel[-3:]
+
+
+@pytest.mark.parametrize("device", _device_params())
+@pytest.mark.parametrize("tag,conv_merging", [("linear_merge", False), ("conv_merge", True)])
+def test_g8_swin_encoder_backbone(golden_dir, debug_core, device, tag, conv_merging):
+    """SURVEY 8 row f-3 / BASELINE config #4: AttnFPN with use_encoder_attn=True.  Swin stages 2-5 (window and
+    shifted-window attention with padding, a grid with one window along two axes, a single-window stage),
+    both patch-merge variants: encoder maps, FPN outputs, state_dict names (checkpoint keys) and the parameter
+    gradients of sum(outputs) against the reference's."""
+    _skip_if_no_gpu(device)
+    from tests._inputs import small_swin_config
+    from transoar_amd.backbone import AttnFPN
+    z = np.load(os.path.join(golden_dir, "g8_swin_backbone.npz"))
+    net = AttnFPN(small_swin_config(conv_merging)).eval()
+    assert list(net.state_dict().keys()) == list(z[tag + ".state_names"])
+    fill_deterministic(net)
+    net = net.to(device)
+    x = analytic_volume((32, 32, 64)).to(device)
+    enc = net._encoder(x)
+    for k in ("C2", "C3", "C4", "C5"):
+        assert relerr(enc[k], z["%s.%s" % (tag, k)]) <= 1e-4, k
+    out = net(x)
+    for k, v in out.items():
+        assert relerr(v, z["%s.%s" % (tag, k)]) <= 1e-4, k
+    total = sum(o.sum() for o in out.values())
+    params = dict(net.named_parameters())
+    assert list(params.keys()) == list(z[tag + ".grad_names"])
+    grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    for name, g, s, a in zip(params, grads, z[tag + ".grad_sums"], z[tag + ".grad_abs_sums"]):
+        got = 0.0 if g is None else g.double().sum().item()
+        # (a weight directly in front of a norm layer has an analytically zero gradient: fp32 noise ~1e-7)
+        assert abs(got - s) <= (2e-4 if device == "cpu" else 5e-3) * max(a, 1e-6) + 2e-6, name
+
+
+def test_swin_stochastic_depth_and_window_layout():
+    """DropPath drops whole samples with probability p and rescales the survivors; the one-gather window
+    layout equals pad + roll + partition written out."""
+    from transoar_amd.swin_encoder import DropPath, effective_window, window_layout
+    torch.manual_seed(0)
+    dp = DropPath(0.25).train()
+    y = dp(torch.ones(4000, 3, 2))
+    kept = y[:, 0, 0] != 0
+    assert torch.all(y[kept] == 1 / 0.75) and abs(float(kept.float().mean()) - 0.75) < 0.03
+    assert torch.equal(dp.eval()(torch.ones(5, 2)), torch.ones(5, 2))
+    grid, window, shift = (4, 7, 12), (5, 5, 5), (2, 2, 2)
+    win, sh = effective_window(grid, window, shift)
+    assert win == (4, 5, 5) and sh == (0, 2, 2)
+    lay = window_layout(grid, win, sh, "cpu")
+    x = torch.arange(4 * 7 * 12, dtype=torch.float32).view(1, 4, 7, 12, 1) + 1
+    pad = torch.nn.functional.pad(x, (0, 0, 0, 3, 0, 3, 0, 0))                      # -> (4, 10, 15)
+    rolled = torch.roll(pad, shifts=(0, -2, -2), dims=(1, 2, 3))
+    ref = rolled.view(1, 1, 4, 2, 5, 3, 5, 1).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(1, 6, 100, 1)
+    tok = torch.cat((x.view(1, -1, 1), torch.zeros(1, 1, 1)), 1)
+    got = tok[:, lay.gather].view(1, lay.n_windows, lay.n_per, 1)
+    assert torch.equal(got, ref)
+    assert torch.equal(got.reshape(1, -1, 1)[:, lay.scatter], x.view(1, -1, 1))

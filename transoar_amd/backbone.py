@@ -14,6 +14,7 @@ from torch import nn
 from . import instnorm
 from .conv3d import Conv3dK3, to_ncdhw
 from .position_encoding import PositionEmbeddingLearned3D, PositionEmbeddingSine3D
+from .swin_encoder import ConvPatchMerging, EncoderSwinBlock, PatchMerging
 from .refine_block import DecoderDefAttnBlock
 
 
@@ -56,15 +57,25 @@ class EncoderCnnBlock(nn.Module):
 class Encoder(nn.Module):
     def __init__(self, config, debug=False):
         super().__init__()
-        if config["use_encoder_attn"]:
-            raise NotImplementedError(
-                "use_encoder_attn=True (Swin stages, encoder_blocks.py:56-400) is out of scope of the "
-                "MI355X hot path build; see DESIGN.md")
         self._debug = debug
         self._stages = nn.ModuleList()
         cin, cout = config["in_channels"], config["start_channels"]
-        for kernel, stride in zip(config["conv_kernels"], config["strides"]):
-            self._stages.append(EncoderCnnBlock(cin, cout, kernel, stride))
+        swin = bool(config["use_encoder_attn"])
+        depths = list(config["depths"])
+        # stochastic-depth rate grows linearly over all Swin blocks (attn_fpn.py:160-162)
+        dpr = [float(v) for v in torch.linspace(0, config["drop_path_rate"], sum(depths))]
+        merge = ConvPatchMerging if config["conv_merging"] else PatchMerging
+        for stage_id, (kernel, stride) in enumerate(zip(config["conv_kernels"], config["strides"])):
+            if swin and stage_id > 1:         # stages 0-1 are the convolutional patch embedding (attn_fpn.py:172)
+                k = stage_id - 2
+                stage = EncoderSwinBlock(
+                    dim=cin, depth=depths[k], num_heads=config["num_heads"][k], window_size=config["window_size"],
+                    mlp_ratio=config["mlp_ratio"], qkv_bias=config["qkv_bias"], qk_scale=config["qk_scale"],
+                    drop=config["drop_rate"], attn_drop=config["attn_drop_rate"],
+                    drop_path=dpr[sum(depths[:k]):sum(depths[:k + 1])], downsample=merge)
+            else:
+                stage = EncoderCnnBlock(cin, cout, kernel, stride)
+            self._stages.append(stage)
             cin, cout = cout, cout * 2
 
     def forward(self, x):

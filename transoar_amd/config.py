@@ -38,15 +38,16 @@ _TOP = dict(
 )
 
 
-def visceral_config(refine=False, use_cuda=True):
+def visceral_config(refine=False, use_cuda=True, swin=False):
     """config/attn_fpn_foc_dec_visceral.yaml: 160x160x256 volumes, 20 organs,
     540 queries, neck on P2.  refine=True switches the deformable-attention
-    refinement on (use_decoder_attn; shipped default is off, yaml:69)."""
+    refinement on (use_decoder_attn; shipped default is off, yaml:69); swin=True the Swin encoder stages
+    (use_encoder_attn, yaml:48: BASELINE.json config #4)."""
     cfg = copy.deepcopy(_TOP)
     cfg.update(experiment_name="foc_dec_visceral", dataset="visceral_160_160_256_CT", num_classes=20,
                volume_shape=(160, 160, 256))
     cfg["backbone"] = copy.deepcopy(_BACKBONE)
-    cfg["backbone"].update(use_decoder_attn=refine, use_cuda=use_cuda)
+    cfg["backbone"].update(use_decoder_attn=refine, use_cuda=use_cuda, use_encoder_attn=swin)
     cfg["neck"] = copy.deepcopy(_NECK)
     return cfg
 

@@ -1,0 +1,233 @@
+"""Swin 3-D window-attention encoder stages (BASELINE config #4:
+``backbone.use_encoder_attn=True``).
+
+Semantics of transoar/models/backbones/encoder_blocks.py:56-400 (Video-Swin blocks as wired by
+attn_fpn.py:172-185): encoder stages 2..5 become ``depth`` pairs of window / shifted-window attention blocks
+over 5x5x5 windows followed by a patch merge that halves the grid and doubles the channels; stages 0-1 stay
+convolutional.  Parameter and buffer names follow the reference (checkpoint keys):
+
+    _stages.#.blocks.#.{norm1,norm2}.{weight,bias}
+    _stages.#.blocks.#.attn.{relative_position_bias_table, relative_position_index, qkv.*, proj.*}
+    _stages.#.blocks.#.mlp.{fc1,fc2}.{weight,bias}
+    _stages.#.downsample.{reduction.weight, norm.*}            (PatchMerging)
+    _stages.#.downsample._reduction.{0.weight, 1.weight, 1.bias}   (ConvPatchMerging)
+
+How it is computed is not the reference's: pad-to-window, cyclic shift and window partition are ONE token
+gather through an index list built once per (grid, window, shift) -- and their inverses one gather back --
+instead of pad + roll + view/permute/contiguous copies each way; the attention of all windows of all samples
+runs as one fused scaled-dot-product call whose additive term (relative-position bias + shifted-window mask)
+is assembled once per block.  Padding tokens are zero vectors that take part in the attention exactly as in
+the reference (it pads AFTER norm1, encoder_blocks.py:158-164).
+"""
+import itertools
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath as the reference uses it): in training a
+    sample's branch is dropped with probability p and the survivors are scaled by 1/(1-p)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+def effective_window(grid, window, shift=None):
+    """Window (and shift) actually used on a grid: an axis not longer than the window is covered by one
+    window and is not shifted (encoder_blocks.py:356-370)."""
+    win = tuple(g if g <= w else w for g, w in zip(grid, window))
+    if shift is None:
+        return win
+    return win, tuple(0 if g <= w else s for g, w, s in zip(grid, window, shift))
+
+
+class _WindowLayout:
+    """Index lists of one (grid, window, shift): which token sits at (window, position) after padding to a
+    multiple of the window and rolling by -shift; the inverse; and the shifted-window mask."""
+
+    def __init__(self, grid, win, shift, device):
+        D, H, W = grid
+        pad = tuple(-(-g // w) * w for g, w in zip(grid, win))
+        Dp, Hp, Wp = pad
+        n_tok = D * H * W
+        # source token of every padded+rolled position: rolled[p] = padded[(p + shift) mod size]
+        axes = [(torch.arange(n) + s) % n for n, s in zip(pad, shift)]
+        d, h, w = torch.meshgrid(*axes, indexing="ij")
+        src = (d * H + h) * W + w
+        src = torch.where((d < D) & (h < H) & (w < W), src, torch.full_like(src, n_tok))     # n_tok = the zero row
+        nd, nh, nw = Dp // win[0], Hp // win[1], Wp // win[2]
+        src = src.view(nd, win[0], nh, win[1], nw, win[2]).permute(0, 2, 4, 1, 3, 5).reshape(-1)
+        self.n_windows, self.n_per = nd * nh * nw, win[0] * win[1] * win[2]
+        self.gather = src.to(device)
+        # inverse: slot (window, position) that holds token t
+        inv = torch.empty(n_tok + 1, dtype=torch.long)
+        inv[src] = torch.arange(src.numel())
+        self.scatter = inv[:n_tok].to(device)
+        self.mask = None
+        if any(s > 0 for s in shift):
+            # region label of every padded position (3 slabs per axis), as seen after the roll
+            # (encoder_blocks.py:373-386): tokens of one window attend only within equal labels
+            label = torch.zeros(pad, dtype=torch.long)
+            cuts = [((0, n - w_), (n - w_, n - s_), (n - s_, n)) for n, w_, s_ in zip(pad, win, shift)]
+            for cnt, (sd, sh, sw) in enumerate(itertools.product(*cuts)):
+                label[sd[0]:sd[1], sh[0]:sh[1], sw[0]:sw[1]] = cnt
+            lab = label.view(nd, win[0], nh, win[1], nw, win[2]).permute(0, 2, 4, 1, 3, 5).reshape(self.n_windows, self.n_per)
+            diff = lab[:, None, :] != lab[:, :, None]
+            self.mask = torch.zeros(diff.shape).masked_fill_(diff, -100.0).to(device)
+
+
+_LAYOUTS = {}
+
+
+def window_layout(grid, win, shift, device):
+    key = (tuple(grid), tuple(win), tuple(shift), str(device))
+    hit = _LAYOUTS.get(key)
+    if hit is None:
+        hit = _LAYOUTS[key] = _WindowLayout(tuple(grid), tuple(win), tuple(shift), device)
+    return hit
+
+
+class WindowAttention3D(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias, qk_scale, attn_drop, proj_drop):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        wd, wh, ww = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), num_heads))
+        # index of the pair (query position, key position) in the table: mixed radix of the offsets
+        pos = torch.stack(torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing="ij")).flatten(1)
+        rel = pos[:, :, None] - pos[:, None, :] + torch.tensor([wd - 1, wh - 1, ww - 1])[:, None, None]
+        index = (rel[0] * (2 * wh - 1) + rel[1]) * (2 * ww - 1) + rel[2]
+        self.register_buffer("relative_position_index", index)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def position_bias(self, n):
+        """(heads, n, n) relative-position bias of the first n positions of the window."""
+        idx = self.relative_position_index[:n, :n].reshape(-1)
+        return self.relative_position_bias_table[idx].view(n, n, -1).permute(2, 0, 1)
+
+    def forward(self, x, mask=None):
+        """x (B, nW, n, C) tokens per window; mask (nW, n, n) additive or None."""
+        b, nw, n, c = x.shape
+        h = self.num_heads
+        q, k, v = self.qkv(x).view(b, nw, n, 3, h, c // h).permute(3, 0, 1, 4, 2, 5)      # each (B, nW, h, n, hd)
+        bias = self.position_bias(n).to(q.dtype)[None]                                    # (1, h, n, n)
+        if mask is not None:
+            bias = bias + mask.to(q.dtype)[:, None]                                        # (nW, h, n, n)
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=bias,
+                                             dropout_p=self.attn_drop.p if self.training else 0.0, scale=self.scale)
+        return self.proj_drop(self.proj(out.transpose(2, 3).reshape(b, nw, n, c)))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop,
+                 drop_path, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.window_size, self.shift_size = tuple(window_size), tuple(shift_size)
+        assert all(0 <= s < w for s, w in zip(self.shift_size, self.window_size)), "shift_size must in 0-window_size"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention3D(dim, self.window_size, num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, grid):
+        """x (B, D*H*W, C) tokens of a (D, H, W) grid."""
+        b, n_tok, c = x.shape
+        win, shift = effective_window(grid, self.window_size, self.shift_size)
+        lay = window_layout(grid, win, shift, x.device)
+        y = self.norm1(x)
+        y = torch.cat((y, y.new_zeros(b, 1, c)), dim=1)                      # row n_tok: the padding token
+        y = y[:, lay.gather].view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
+        y = self.attn(y, lay.mask)
+        y = y.reshape(b, -1, c)[:, lay.scatter]                              # merge + shift back + crop
+        x = x + self.drop_path(y)
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchMerging(nn.Module):
+    """2x2x2 neighbours -> 8C channels -> LayerNorm -> Linear(8C, 2C, no bias) (encoder_blocks.py:298-327).
+    Channel blocks in the reference's order: for d-offset 0,1: (h0,w0), (h1,w0), (h0,w1), (h1,w1).  Odd H/W are
+    zero padded; D is not (sic)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(8 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(8 * dim)
+
+    def forward(self, x):
+        b, d, h, w, c = x.shape
+        if h % 2 or w % 2:
+            x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2))
+            h, w = h + h % 2, w + w % 2
+        x = x[:, : d - d % 2]                                   # stride-2 slicing of the reference drops a last odd plane
+        x = x.view(b, d // 2, 2, h // 2, 2, w // 2, 2, c)       # (b, D, dd, H, dh, W, dw, c)
+        x = x.permute(0, 1, 3, 5, 2, 6, 4, 7).reshape(b, d // 2, h // 2, w // 2, 8 * c)     # blocks ordered (dd, dw, dh)
+        return self.reduction(self.norm(x))
+
+
+class ConvPatchMerging(nn.Module):
+    def __init__(self, dim, bias=False, affine=True, eps=1e-05):
+        super().__init__()
+        self._reduction = nn.Sequential(
+            nn.Conv3d(dim, dim * 2, kernel_size=2, stride=2, padding=0, bias=bias),
+            nn.InstanceNorm3d(dim * 2, affine=affine, eps=eps), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self._reduction(x.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+
+
+class EncoderSwinBlock(nn.Module):
+    """One Swin stage: ``depth`` blocks alternating plain / shifted windows, then the patch merge."""
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path,
+                 downsample, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.blocks = nn.ModuleList(
+            SwinBlock(dim, num_heads, self.window_size, (0, 0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, qkv_bias,
+                      qk_scale, drop, attn_drop, drop_path[i] if isinstance(drop_path, (list, tuple)) else drop_path,
+                      norm_layer=norm_layer)
+            for i in range(depth))
+        self.downsample = None
+        if downsample is not None:
+            self.downsample = downsample(dim=dim) if downsample is ConvPatchMerging else downsample(dim=dim, norm_layer=norm_layer)
+
+    def forward(self, x):
+        """x (B, C, D, H, W) -> (B, 2C, D/2, H/2, W/2) (or (B, C, D, H, W) without a downsample)."""
+        b, c, d, h, w = x.shape
+        tokens = x.flatten(2).transpose(1, 2)                  # a free view for channels-last input
+        for blk in self.blocks:
+            tokens = blk(tokens, (d, h, w))
+        y = tokens.view(b, d, h, w, c)
+        if self.downsample is not None:
+            y = self.downsample(y)
+        return y.permute(0, 4, 1, 2, 3)
