@@ -63,7 +63,8 @@ enum {
   TRANSOAR_ERR_DTYPE = -3,       /* unsupported dtype combination         */
   TRANSOAR_ERR_ALIGN = -4,       /* a buffer is not 16-byte aligned       */
   TRANSOAR_ERR_LEVELS = -5,      /* L > TRANSOAR_MSDA3D_MAX_LEVELS        */
-  TRANSOAR_ERR_WORKSPACE = -6    /* workspace smaller than required       */
+  TRANSOAR_ERR_WORKSPACE = -6,   /* workspace smaller than required       */
+  TRANSOAR_ERR_CONST = -7        /* device copy of the launch constants could not be made (first call for a shape inside a stream capture) */
 };
 
 #define TRANSOAR_MSDA3D_MAX_LEVELS 8

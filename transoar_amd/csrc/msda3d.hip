@@ -19,7 +19,9 @@
 #include "msda3d_generic.hpp"
 #include "msda3d_scatter.hpp"
 
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace transoar {
@@ -140,6 +142,34 @@ static inline long order_units(const BrickOrder& o, const Dims& d, int rows) {
 
 static inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
 
+// Launch constants of the brick-scheduled kernels (BrickOrder: ~300 bytes; CoarseLevels) live in device memory and
+// the kernels read them through a pointer: kernel arguments stay a handful of scalars and pointers, which is what
+// replays correctly from a captured HIP graph with ROCm's graph packet capture (large by-value kernel arguments
+// are the suspect of the corrupted replays of DESIGN.md section 8).  One immutable copy per distinct content and
+// device, made on first use -- a synchronous hipMalloc + hipMemcpy, so first use must be an eager call (the
+// training step always runs eagerly before it is captured); returns nullptr if that is not possible.
+static const void* device_const(const void* host, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, std::string>, void*> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::pair<int, std::string> key(dev, std::string(static_cast<const char*>(host), bytes));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
+  cache[key] = p;
+  return p;
+}
+template <typename T> static const T* device_const(const T& v) {
+  return static_cast<const T*>(device_const(&v, sizeof(T)));
+}
+
 // Can the vector kernels run this problem?  (32-bit byte offsets into value,
 // 32-bit bin / point indices.)
 static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
@@ -204,8 +234,10 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
       ProfScope prof(TRANSOAR_PROF_FWD, st);
       const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 4;
       const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
+      const BrickOrder* order_d = device_const(order);
+      if (order_d == nullptr) return TRANSOAR_ERR_CONST;
       hipLaunchKernelGGL((msda3d_fwd_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
-                         v, lo, at, o, d.S, d.M, d.L, vbytes, n_wave, order);
+                         v, lo, at, o, d.S, d.M, d.L, vbytes, n_wave, order_d);
       return static_cast<int>(hipGetLastError());
     }
   }
@@ -319,9 +351,11 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
       ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
       const long n_wave = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M * 4;
+      const BrickOrder* order_d = device_const(q_order);
+      if (order_d == nullptr) return TRANSOAR_ERR_CONST;
       hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                          v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes,
-                         n_wave, q_order);
+                         n_wave, order_d);
       brick_done = true;
     }
   }
@@ -382,6 +416,9 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       const int coarse_levels = d.L - cl.first;
       cl.chunks_per_slab = static_cast<int>((static_cast<long>(d.Lq) * d.P * coarse_levels + kCellChunk - 1) / kCellChunk) + 1;
       const int fine_bricks = r_order.pad_start[cl.first] >> 7;
+      const BrickOrder* r_order_d = device_const(r_order);
+      const CoarseLevels* cl_d = device_const(cl);
+      if (r_order_d == nullptr || cl_d == nullptr) return TRANSOAR_ERR_CONST;
       float* scratch = reinterpret_cast<float*>(ws + w.coarse);
       const long scratch_elems = static_cast<long>(d.N) * cl.rows * d.M * kTileC;
       // opt-in (TRANSOAR_MSDA3D_FORK): 3.90 -> 3.59 ms per eager backward at the flagship, but 1.1 ms per
@@ -399,8 +436,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         TRANSOAR_CHECK_HIP(zero_async(scratch, sizeof(float) * scratch_elems, cst));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
         hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
-                           go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl,
-                           r_order);
+                           go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl_d,
+                           r_order_d);
       }
       if (side != nullptr) TRANSOAR_CHECK_HIP(hipEventRecord(side->join, side->stream));
       ProfScope prof(TRANSOAR_PROF_VALUE_TILE, st);
@@ -408,13 +445,13 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
         hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
                            count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
-                           d.S, d.M, fine_bricks, n_wg, r_order);
+                           d.S, d.M, fine_bricks, n_wg, r_order_d);
       }
       if (side != nullptr) TRANSOAR_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
       if (coarse_levels > 0) {
         const long n4 = scratch_elems / 4;
         hipLaunchKernelGGL((msda3d_coarse_rows_store<VT>), dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, st,
-                           scratch, static_cast<VT*>(grad_value), d.S, d.M, cl, n4);
+                           scratch, static_cast<VT*>(grad_value), d.S, d.M, cl.rows, cl.row_start, n4);
       }
       return static_cast<int>(hipGetLastError());
     }
@@ -537,6 +574,7 @@ extern "C" const char* transoar_msda3d_strerror(int code) {
     case TRANSOAR_ERR_ALIGN: return "a device buffer is not 16-byte aligned";
     case TRANSOAR_ERR_LEVELS: return "too many feature levels";
     case TRANSOAR_ERR_WORKSPACE: return "workspace is smaller than transoar_msda3d_backward_workspace_bytes()";
+    case TRANSOAR_ERR_CONST: return "could not place the launch constants in device memory (first call for a shape must not be inside a stream capture)";
     default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
   }
 }

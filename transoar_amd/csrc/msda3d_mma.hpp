@@ -116,7 +116,8 @@ struct MmaBox {       // wave-uniform: corner-voxel bounding box of the wave's p
 template <typename VT, typename LT>
 __global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
     const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
-    VT* __restrict__ out, int S, int M, int L, unsigned value_bytes, long n_units, BrickOrder order) {
+    VT* __restrict__ out, int S, int M, int L, unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
+  const BrickOrder& order = *order_p;      // device-resident launch constants (msda3d.hip: device_const)
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
   __shared__ __attribute__((aligned(16))) float wbuf[WR * 32];      // [column][query]: query-fastest, bank = query
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
     const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
     int* __restrict__ bin_count, int* __restrict__ bin_rank, int cells_per_slab, int S, int M, int L,
-    unsigned value_bytes, long n_units, BrickOrder order) {
+    unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
+  const BrickOrder& order = *order_p;
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
   __shared__ __attribute__((aligned(16))) float gbuf[WR * 32];      // G block [row][query] (+ a zero spare row); the cell histogram before that

@@ -57,7 +57,8 @@ template <typename VT>
 __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_value_tile(
     const VT* __restrict__ grad_out, const int* __restrict__ offset,
     const PointW8<float>* __restrict__ recs, const int* __restrict__ rec_item,
-    VT* __restrict__ grad_value, int cells_per_slab, int S, int M, int fine_bricks, long n_wg, BrickOrder order) {
+    VT* __restrict__ grad_value, int cells_per_slab, int S, int M, int fine_bricks, long n_wg, const BrickOrder* __restrict__ order_p) {
+  const BrickOrder& order = *order_p;      // device-resident launch constants (msda3d.hip: device_const)
   constexpr int C = kTileC;
   constexpr int U = 4;                            // weight records per scalar-load round
   constexpr int G = 16;                           // grad_out rows in flight per wave
@@ -211,8 +212,10 @@ template <typename VT>
 __global__ __launch_bounds__(256) void msda3d_bwd_value_cells(
     const VT* __restrict__ grad_out, const int* __restrict__ offset,
     const PointW8<float>* __restrict__ recs, const int* __restrict__ rec_item,
-    float* __restrict__ scratch, int cells_per_slab, int n_slabs, int M, CoarseLevels cl,
-    BrickOrder order) {
+    float* __restrict__ scratch, int cells_per_slab, int n_slabs, int M, const CoarseLevels* __restrict__ cl_p,
+    const BrickOrder* __restrict__ order_p) {
+  const CoarseLevels& cl = *cl_p;
+  const BrickOrder& order = *order_p;
   constexpr int C = kTileC;
   constexpr int U = 4, G = 16;
   const int lane = threadIdx.x & 63;
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(256) void msda3d_bwd_value_cells(
 template <typename VT>
 __global__ __launch_bounds__(256) void msda3d_coarse_rows_store(const float* __restrict__ scratch,
                                                                 VT* __restrict__ grad_value, int S, int M,
-                                                                CoarseLevels cl, long n) {
+                                                                int cl_rows, int cl_row_start, long n) {
+  struct { int rows, row_start; } cl{cl_rows, cl_row_start};
   const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;    // one float4 each
   if (i >= n) return;
   constexpr int V4 = kTileC / 4;

@@ -42,6 +42,7 @@ class TrainStep:
         self.amp_dtype = amp_dtype
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=graph)
         self._graph = None
+        self._replay_done = None
         self._static_counts = None
         self._expect_total = None
         self._want_graph = graph
@@ -123,6 +124,8 @@ class TrainStep:
         with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
             self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
         self._graph = graph
+        # TRANSOAR_GRAPH_SERIALIZE=1: never launch the graph again before its previous launch has finished on the GPU
+        self._replay_done = torch.cuda.Event() if os.environ.get("TRANSOAR_GRAPH_SERIALIZE") else None
         return self
 
     def capture_stream(self):
@@ -152,6 +155,8 @@ class TrainStep:
         self._static_counts.copy_(self._local_counts(self._static_t))
         if self.reducer.active:
             self.reducer.reduce_counts(self._static_counts)
+        if self._replay_done is not None:
+            self._replay_done.synchronize()      # the previous step (replay + all-reduce + AdamW) has left the GPU: see capture()
         self._graph.replay()
         if self._expect_total is not None:
             expect, self._expect_total = self._expect_total, None
@@ -167,6 +172,8 @@ class TrainStep:
                 b.handle.wait()
         self._clip()
         self.optimizer.step()
+        if self._replay_done is not None:
+            self._replay_done.record()
         return self._static_total, self._static_losses
 
     def drop_graph(self):
