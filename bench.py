@@ -266,7 +266,8 @@ def main():
         try:
             step.capture(x, targets)
             step(x, targets)                   # first replay: TrainStep checks its loss against the eager step's
-            step_mode = "hip-graph(fwd+loss+bwd) + eager all-reduce + fused AdamW"
+            step_mode = ("hip-graph(fwd+loss+bwd+AdamW)" if step.capture_optimizer else
+                         "hip-graph(fwd+loss+bwd) + eager all-reduce + fused AdamW")
         except Exception as e:                 # keep going eagerly, say so in the output
             import traceback
             traceback.print_exc()
