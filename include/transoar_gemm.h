@@ -1,0 +1,37 @@
+/*
+ * transoar_gemm.h -- C ABI of the gfx950 bf16/f16 token GEMM  C = A . B^T (+ bias) (ReLU).
+ *
+ * Replaces, on the refinement block's 234 000-token projections, what the reference reaches through
+ * nn.Linear -> cuBLAS under autocast: ops/modules/ms_deform_attn.py:109-140 (value_proj, sampling_offsets,
+ * attention_weights, output_proj) and backbones/decoder_blocks.py:157-174 (linear1 + ReLU, linear2), forward
+ * and data gradient (dX = dY . W is the same NT product with W^T as the B operand).
+ *
+ *   A    (M, K) row-major, leading dimension lda (elements)     activations / output gradients
+ *   B    (N, K) row-major, leading dimension ldb                nn.Linear's weight layout
+ *   bias (N,) fp32 or NULL
+ *   C    (M, N) row-major, leading dimension ldc; out_dtype = in_dtype (bf16/f16) or TRANSOAR_GEMM_F32
+ * K a multiple of 8, N a multiple of 4, lda/ldb multiples of 8, ldc of 4; buffers 16-byte aligned; fp32
+ * accumulation.  Asynchronous on `hip_stream`.  Returns 0, a negative argument error, or a hipError_t.
+ */
+#ifndef TRANSOAR_GEMM_H
+#define TRANSOAR_GEMM_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TRANSOAR_GEMM_F32 = 0, TRANSOAR_GEMM_BF16 = 2, TRANSOAR_GEMM_F16 = 3 };
+enum {
+  TRANSOAR_GEMM_ERR_NULL = -1,
+  TRANSOAR_GEMM_ERR_DIM = -2,
+  TRANSOAR_GEMM_ERR_DTYPE = -3,
+  TRANSOAR_GEMM_ERR_ALIGN = -4
+};
+
+int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
+                     int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream);
+int transoar_gemm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSOAR_GEMM_H */

@@ -29,6 +29,37 @@ def test_library_exports_every_declared_symbol():
     assert _native.lib.transoar_msda3d_abi_version() == _native.ABI_VERSION
 
 
+def test_every_header_under_include_has_its_library_and_symbols():
+    """include/transoar_<name>.h  <->  transoar_amd/libtransoar_<name>.so: every function a header declares is
+    exported by the library of the same name."""
+    inc = os.path.join(ROOT, "include")
+    seen = 0
+    for fn in sorted(os.listdir(inc)):
+        m = re.match(r"transoar_([a-z0-9]+)\.h$", fn)
+        if not m:
+            continue
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, fn)).read(), flags=re.S)
+        syms = sorted(set(re.findall(r"\b(transoar_[a-z_0-9]+)\s*\(", text)))
+        lib = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_%s.so" % m.group(1)))
+        assert syms, fn
+        for s in syms:
+            assert hasattr(lib, s), (fn, s)
+        seen += 1
+    assert seen >= 6
+
+
+def test_gemm_argument_errors():
+    lib = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_gemm.so"))
+    buf = (ctypes.c_char * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    f = lib.transoar_gemm_nt
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 9 + [ctypes.c_void_p]
+    assert f(None, p16, None, p16, 8, 8, 8, 8, 8, 8, 2, 2, 0, None) == -1
+    assert f(p16, p16, None, p16, 8, 8, 12, 12, 12, 8, 2, 2, 0, None) == -2       # K not a multiple of 8
+    assert f(p16, p16, None, p16, 8, 8, 8, 8, 8, 8, 0, 0, 0, None) == -3          # fp32 operands
+    assert f(p16 + 2, p16, None, p16, 8, 8, 8, 8, 8, 8, 2, 2, 0, None) == -4
+
+
 def test_argument_errors_are_returned_not_printed():
     from transoar_amd import _native
     lib = _native.lib
@@ -49,7 +80,7 @@ def test_argument_errors_are_returned_not_printed():
     assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, None, p16, p16, p16, None, 0, *dims_ok, 0, 0, None, 0, None) == -1
     assert lib.transoar_msda3d_backward(p16, p16, p16, p16, p16, p16, p16, p16, p16, None, 0, 2, 1000, 6, 64, 1, 10, 4, 0, 0, None, 0, None) == -6
     assert lib.transoar_msda3d_backward_workspace_bytes(2, 1000, 6, 64, 1, 10, 4, 0, 0, 0) > 0
-    for code in (0, -1, -2, -3, -4, -5, -6):
+    for code in (0, -1, -2, -3, -4, -5, -6, -7):
         assert len(lib.transoar_msda3d_strerror(code)) > 0
 
 

@@ -1,0 +1,74 @@
+"""GPU: the hand-written bf16/f16 MFMA token GEMM (csrc/gemm.hip) against a plain PyTorch fp32 matmul of the
+same 16-bit-rounded operands.  fp32 accumulation both sides -> only the output rounding (and summation order)
+differs: 2^-8 (bf16) / 2^-11 (f16) of the largest |value|; fp32 output 1e-5."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, bias, relu):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    return y.relu() if relu else y
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 384, 384), (4099, 1024, 384), (300, 384, 1024), (777, 64, 100), (128, 8, 4),
+                                    (234000, 384, 384)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_nt_matches_fp32_matmul(m, k, n, dt):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(m + k + n)
+    x = torch.randn(m, k, device="cuda", generator=g).to(dt)
+    w = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).to(dt)
+    b = torch.randn(n, device="cuda", generator=g)
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    for bias, relu in ((None, False), (b, False), (b, True)):
+        want = _ref(x, w, bias, relu)
+        got = gemm.linear_nt(x, w, bias, relu)
+        assert got.dtype == dt and got.shape == (m, n)
+        assert float((got.float() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6
+    got32 = gemm.linear_nt(x, w, b, False, out_dtype=torch.float32)
+    assert float((got32 - _ref(x, w, b, False)).abs().max()) <= 1e-5 * float(_ref(x, w, b, False).abs().max()) + 1e-6
+
+
+def test_gemm_nt_strided_operands_and_asymmetry():
+    """Row-strided views (lda > K) and an asymmetric B: a row/column swap in the C write cannot pass."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd import gemm
+    big = torch.arange(520 * 96, device="cuda", dtype=torch.float32).view(520, 96).remainder(7).sub(3).to(torch.bfloat16)
+    x = big[:, 16:80]                                      # (520, 64), lda 96
+    w = torch.zeros(36, 64, device="cuda", dtype=torch.bfloat16)
+    w[torch.arange(36), torch.arange(36)] = torch.arange(1, 37, device="cuda").to(torch.bfloat16)     # scaled selector
+    got = gemm.linear_nt(x, w)
+    want = x.float()[:, :36] * torch.arange(1, 37, device="cuda")
+    assert torch.equal(got.float(), want.to(torch.bfloat16).float())
+
+
+def test_token_linear_runs_on_the_hand_written_gemm():
+    """token_linear (the refine block's projections under bf16 autocast): forward and input gradient come from
+    csrc/gemm.hip, the weight gradient from the chunked reduction; all three against fp32 autograd."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd import token_linear as tl
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2, 40000, 384, device="cuda", generator=g).to(torch.bfloat16).requires_grad_()
+    lin = torch.nn.Linear(384, 1024).cuda()
+    gy = torch.randn(2, 40000, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = tl.token_linear(x, lin.weight, lin.bias)
+    assert tl.LAST_PATH == "hip-gemm"
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_()
+    wr = lin.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr, lin.bias.detach())
+    yr.backward(gy.float())
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())
+    assert rel(y, yr) <= 2.0 ** -7
+    assert rel(x.grad, xr.grad) <= 2.0 ** -7
+    assert rel(lin.weight.grad, wr.grad) <= 2e-3
+    assert rel(lin.bias.grad, gy.float().sum((0, 1))) <= 1e-3

@@ -21,6 +21,7 @@ LIBS = {
     "libtransoar_instnorm.so": ["instnorm.hip"],
     "libtransoar_rows.so": ["rows.hip"],
     "libtransoar_tokens.so": ["tokens.hip"],
+    "libtransoar_gemm.so": ["gemm.hip"],
 }
 
 

@@ -1,0 +1,209 @@
+// bf16 token GEMM for gfx950:  C[M][N] = A[M][K] . B[N][K]^T (+ bias[N]) (ReLU), fp32 accumulate.
+//
+// The projections of the deformable-attention refinement (value / output / stacked offsets|attention, FFN
+// 384 -> 1024 -> 384; ops/modules/ms_deform_attn.py:109-140, backbones/decoder_blocks.py:157-174) and their
+// data gradients: M = 234 000 tokens at batch 2, K and N in {384, 1024}.  Both operands are K-contiguous
+// ("NT"), which is nn.Linear's own layout (x (M, K), weight (N, K)): no transposes anywhere.
+//
+//   * 256 threads = 4 waves (2 x 2), block tile 128 x 128, K step 64; a wave owns 64 x 64 = 2 x 2 MFMA tiles
+//     of v_mfma_f32_32x32x16 (bf16 or f16), 16 MFMAs per K step;
+//   * operand tiles are [128 rows][64 K] = 128-byte rows in LDS with the 16-byte pieces XOR-swizzled by the
+//     row (piece ^ (row & 7)): the ds_read_b128 of an MFMA fragment (32 rows, one piece each) spreads over all
+//     banks; two LDS stages, global -> registers -> LDS staging with the next tile's loads in flight during the
+//     MFMAs (one barrier per K step);
+//   * the MFMAs are issued with the WEIGHT tile as the A operand, so D = C^T tiles come out [n][m]: a lane
+//     holds 4 consecutive n of one token and stores 8 (bf16) or 16 (fp32) bytes;
+//   * raw buffer loads: rows past M or N read as zeros, no edge branches in the main loop;
+//   * XCD-contiguous block order with the N tiles of one M stripe adjacent (they re-read the same A rows).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_gemm.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = 128 * BK * 2;                 // one operand tile: 16 KiB
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+__device__ __forceinline__ unsigned short f32_to_f16(float f) {
+  return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));
+}
+
+// block id -> (m tile, n tile): each XCD walks a contiguous eighth of the tiles, n fastest
+__device__ __forceinline__ long xcd_contiguous(long bid, long n) {
+  const long per = (n + 7) >> 3;
+  const long swz = (bid & 7) * per + (bid >> 3);
+  return swz < n ? swz : -1;
+}
+
+template <bool F16, bool OUT_F32, bool RELU>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
+    void* __restrict__ Cout, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kTileBytes];     // [stage][A|B]
+  const long t = xcd_contiguous(blockIdx.x, n_tiles);
+  if (t < 0) return;
+  const int tm = static_cast<int>(t / tiles_n), tn = static_cast<int>(t % tiles_n);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;                   // wave's 64 x 64 quadrant of the block tile
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(A), 0, static_cast<int>(static_cast<long>(M) * lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(B), 0, static_cast<int>(static_cast<long>(N) * ldb * 2), 0x00020000);
+
+  // staging: thread -> (row, 16-byte piece) x 4 per operand.  The row's pieces past K read as zeros (offset
+  // clamp below), rows past M / N are beyond the buffer: zeros as well.
+  const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + 32 i
+  unsigned a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = s_row + 32 * i;
+    a_off[i] = (m0 + r) < M ? static_cast<unsigned>(m0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0xfffffff0u;
+    b_off[i] = (n0 + r) < N ? static_cast<unsigned>(n0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0xfffffff0u;
+  }
+  u32x4 ra_regs[4], rb_regs[4];
+  auto load_tile = [&](int kt) {
+    const unsigned kbyte = static_cast<unsigned>(kt) * BK * 2u;
+    const bool in_k = kt * BK + s_piece * 8 < K;             // K is a multiple of 8 (checked on the host)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] + kbyte : 0xfffffff0u, 0, 0);
+      rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] + kbyte : 0xfffffff0u, 0, 0);
+    }
+  };
+  auto store_tile = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = s_row + 32 * i;
+      const int off = r * 128 + ((s_piece ^ (r & 7)) << 4);
+      *reinterpret_cast<u32x4*>(&lds[stage][0][off]) = ra_regs[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][1][off]) = rb_regs[i];
+    }
+  };
+
+  f32x16 acc[2][2];          // [n tile][m tile] of the wave's quadrant, D = [n][m]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const int KT = (K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 31, kg = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const unsigned char* ta = lds[stage][0];
+    const unsigned char* tb = lds[stage][1];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 fa[2], fb[2];
+      const int piece = 2 * ks + kg;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rm = wm * 64 + i * 32 + fr, rn = wn * 64 + i * 32 + fr;
+        fa[i] = *reinterpret_cast<const s16x8*>(ta + rm * 128 + ((piece ^ (rm & 7)) << 4));
+        fb[i] = *reinterpret_cast<const s16x8*>(tb + rn * 128 + ((piece ^ (rn & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma<F16>(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
+    }
+    if (kt + 1 < KT) store_tile(stage ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds token m = .. + fr, n = .. + 8 q + 4 kg + (0..3)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int m = m0 + wm * 64 + b * 32 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
+        if (n >= N) continue;                                   // N is a multiple of 4 (host check)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[a][b][4 * q + e] + (bias != nullptr ? bias[n + e] : 0.f);
+          if (RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (OUT_F32) {
+          *reinterpret_cast<float4*>(static_cast<float*>(Cout) + static_cast<long>(m) * ldc + n) = float4{v[0], v[1], v[2], v[3]};
+        } else {
+          unsigned short h[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = F16 ? f32_to_f16(v[e]) : f32_to_bf16(v[e]);
+          *reinterpret_cast<uint2*>(static_cast<unsigned short*>(Cout) + static_cast<long>(m) * ldc + n) =
+              uint2{static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16), static_cast<unsigned>(h[2]) | (static_cast<unsigned>(h[3]) << 16)};
+        }
+      }
+    }
+  }
+}
+
+template <bool F16, bool OUT_F32>
+int launch(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc, int relu,
+           hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const long n_tiles = static_cast<long>(tiles_m) * tiles_n;
+  const dim3 grid(static_cast<unsigned>(((n_tiles + 7) / 8) * 8));
+  auto a = static_cast<const unsigned short*>(A);
+  auto b = static_cast<const unsigned short*>(B);
+  if (relu)
+    hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, true>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, ldc, n_tiles, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, false>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, ldc, n_tiles, tiles_n);
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream) {
+  if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7) || (ldc & 3))
+    return TRANSOAR_GEMM_ERR_DIM;
+  if (static_cast<long>(N) * ldb * 2 >= 0x7ffffff0L || static_cast<long>(M) * lda * 2 >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15u) return TRANSOAR_GEMM_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const bool f16 = in_dtype == TRANSOAR_GEMM_F16;
+  if (in_dtype != TRANSOAR_GEMM_BF16 && !f16) return TRANSOAR_GEMM_ERR_DTYPE;
+  if (out_dtype == TRANSOAR_GEMM_F32) return f16 ? launch<true, true>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st)
+                                                 : launch<false, true>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st);
+  if (out_dtype != in_dtype) return TRANSOAR_GEMM_ERR_DTYPE;
+  return f16 ? launch<true, false>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st)
+             : launch<false, false>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st);
+}
+
+extern "C" int transoar_gemm_abi_version(void) { return 1; }

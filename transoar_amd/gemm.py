@@ -1,0 +1,57 @@
+"""ctypes binding of the gfx950 token GEMM (include/transoar_gemm.h): ``linear_nt(x, w, bias, relu)`` =
+``relu?(x @ w.T + bias)`` for bf16/f16 operands with fp32 accumulation.  No fallback: raises if the library is
+missing."""
+import ctypes
+import os
+
+import torch
+
+from . import _native  # noqa: F401  (torch's HIP runtime first)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
+ABI_VERSION = 1
+_DT = {torch.float32: 0, torch.bfloat16: 2, torch.float16: 3}
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise _native.NativeLibraryError("%s is not built (python transoar_amd/_build.py)" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    i, p = ctypes.c_int, ctypes.c_void_p
+    lib.transoar_gemm_nt.restype = i
+    lib.transoar_gemm_nt.argtypes = [p, p, p, p] + [i] * 9 + [p]
+    lib.transoar_gemm_abi_version.restype = i
+    if lib.transoar_gemm_abi_version() != ABI_VERSION:
+        raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
+    return lib
+
+
+lib = _load()
+
+
+def usable(x, w):
+    """2-D row-major 16-bit operands the kernel takes as they are."""
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.dim() == 2 and w.dim() == 2
+            and x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] == w.shape[1] and x.shape[1] % 8 == 0
+            and w.shape[0] % 4 == 0 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and x.shape[0] * x.stride(0) * 2 < 0x7ffffff0)
+
+
+def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
+    """x (M, K), w (N, K) -> (M, N) = x @ w.T (+ bias) (ReLU); bias fp32 (N,)."""
+    if not usable(x, w):
+        raise RuntimeError("transoar_gemm_nt: operands must be 2-D row-major bf16/f16 CUDA tensors with K % 8 == 0, N % 4 == 0")
+    m, k = x.shape
+    n = w.shape[0]
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_gemm_nt(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
+                                  m, n, k, x.stride(0), w.stride(0), n, _DT[x.dtype], _DT[out_dtype], 1 if relu else 0,
+                                  torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_nt failed with code %d" % rc)
+    return out

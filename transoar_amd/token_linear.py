@@ -1,6 +1,7 @@
 """nn.Linear over the flattened feature pyramid (10^5 tokens per volume).
 
-Forward and input gradient are ordinary hipBLASLt GEMMs.  The weight gradient
+Forward and input gradient run on the hand-written bf16 MFMA GEMM (csrc/gemm.hip: x (T, K) . W (N, K)^T with the
+bias in the epilogue; dX = dY . W is the same product with W^T as the (N, K)-shaped operand).  The weight gradient
 dW = dY^T X contracts over the TOKEN axis (K = 234 000 at batch 2) into a tile
 of at most 1024 x 384: hipBLASLt covers that with a few dozen workgroups on a
 256-CU part (0.5-0.9 ms, 40-230 TFLOP/s measured).  Here the token axis is cut
@@ -16,7 +17,10 @@ import os
 import torch
 import torch.nn.functional as F
 
+from . import gemm
+
 MIN_TOKENS = 32768          # below this the stock path is as fast
+LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
 
 
 def _chunks(tokens, n_out, n_in):
@@ -46,6 +50,13 @@ class _TokenLinear(torch.autograd.Function):
         wb = weight.to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
         ctx.in_dtype, ctx.has_bias = x.dtype, bias is not None
+        global LAST_PATH
+        x2 = xb.reshape(-1, xb.shape[-1])
+        if gemm.usable(x2, wb):
+            LAST_PATH = "hip-gemm"
+            # the bias is added in fp32 before the single rounding to bf16 (F.linear rounds the bias to bf16 first)
+            return gemm.linear_nt(x2, wb, bias).view(*xb.shape[:-1], wb.shape[0])
+        LAST_PATH = "blas"
         with torch.autocast("cuda", enabled=False):
             return F.linear(xb, wb, None if bias is None else bias.to(torch.bfloat16))
 
@@ -59,7 +70,9 @@ class _TokenLinear(torch.autograd.Function):
         gx = gw = gb = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
-                gx = torch.mm(gy2, wb).view(xb.shape).to(ctx.in_dtype)
+                wt = wb.t().contiguous()                   # (K, N): dX = dY . W as an NT product
+                gx = gemm.linear_nt(gy2, wt) if gemm.usable(gy2, wt) else torch.mm(gy2, wb)
+                gx = gx.view(xb.shape).to(ctx.in_dtype)
             if ctx.needs_input_grad[1]:
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
             if ctx.has_bias and ctx.needs_input_grad[2]:
