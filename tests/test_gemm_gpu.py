@@ -55,6 +55,7 @@ def test_token_linear_runs_on_the_hand_written_gemm():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from transoar_amd import token_linear as tl
+    tl.USE_HIP_GEMM = True
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(2, 40000, 384, device="cuda", generator=g).to(torch.bfloat16).requires_grad_()
     lin = torch.nn.Linear(384, 1024).cuda()
@@ -72,3 +73,4 @@ def test_token_linear_runs_on_the_hand_written_gemm():
     assert rel(x.grad, xr.grad) <= 2.0 ** -7
     assert rel(lin.weight.grad, wr.grad) <= 2e-3
     assert rel(lin.bias.grad, gy.float().sum((0, 1))) <= 1e-3
+    tl.USE_HIP_GEMM = bool(__import__("os").environ.get("TRANSOAR_HIP_GEMM"))

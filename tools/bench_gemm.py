@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""csrc/gemm.hip vs hipBLASLt (torch F.linear) on the refine block's token shapes, bf16, bias in the epilogue."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transoar_amd import gemm  # noqa: E402
+
+
+def time_ms(fn, iters=20):
+    for _ in range(3):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return ts[len(ts) // 2]
+
+
+for m, k, n in ((234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (204800, 384, 384)):
+    x = torch.randn(m, k, device="cuda").bfloat16()
+    w = (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()
+    b = torch.randn(n, device="cuda")
+    bb = b.bfloat16()
+    ours = time_ms(lambda: gemm.linear_nt(x, w, b))
+    blas = time_ms(lambda: torch.nn.functional.linear(x, w, bb))
+    fl = 2.0 * m * k * n
+    print(json.dumps({"M": m, "K": k, "N": n, "ours_ms": round(ours, 4), "hipblaslt_ms": round(blas, 4),
+                      "ours_TFs": round(fl / ours / 1e9, 1), "hipblaslt_TFs": round(fl / blas / 1e9, 1),
+                      "frac_of_2.5PF": round(fl / ours / 1e9 / 2500, 3)}), flush=True)

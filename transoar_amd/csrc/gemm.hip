@@ -141,33 +141,69 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
     __syncthreads();
   }
 
-  // epilogue: lane holds token m = .. + fr, n = .. + 8 q + 4 kg + (0..3)
+  // epilogue.  A lane holds token m = .. + fr, outputs n = .. + 8 q + 4 kg + (0..3): stored straight from the
+  // registers that would be 8-byte pieces scattered over 64 rows per instruction.  The wave's 64 x 64 tile goes
+  // through its own LDS region instead (row pitch padded by 16 bytes against bank conflicts) and leaves as
+  // whole rows: 16 bytes per lane, 8 (4 for fp32) consecutive rows of 128 (256) contiguous bytes per store.
+  constexpr int ELT = OUT_F32 ? 4 : 2;
+  constexpr int PITCH = 64 * ELT + 16;
+  unsigned char* stage = &lds[0][0][0] + wave * (64 * PITCH);          // 4 x 64 x 272 = 68 KiB would not fit for fp32:
+  static_assert(4 * 64 * (64 * 2 + 16) <= 4 * kTileBytes, "bf16 staging fits");
+  // (the main loop's last barrier has passed: every wave is done reading the operand tiles)
+  if constexpr (!OUT_F32) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int m = m0 + wm * 64 + b * 32 + fr;
-    if (m >= M) continue;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
-        if (n >= N) continue;                                   // N is a multiple of 4 (host check)
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[a][b][4 * q + e] + (bias != nullptr ? bias[n + e] : 0.f);
-          if (RELU) v[e] = fmaxf(v[e], 0.f);
-        }
-        if constexpr (OUT_F32) {
-          *reinterpret_cast<float4*>(static_cast<float*>(Cout) + static_cast<long>(m) * ldc + n) = float4{v[0], v[1], v[2], v[3]};
-        } else {
+        for (int q = 0; q < 4; ++q) {
+          const int nl = a * 32 + 8 * q + 4 * kg;                       // column inside the wave tile
           unsigned short h[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = F16 ? f32_to_f16(v[e]) : f32_to_bf16(v[e]);
-          *reinterpret_cast<uint2*>(static_cast<unsigned short*>(Cout) + static_cast<long>(m) * ldc + n) =
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn * 64 + nl + e;
+            float v = acc[a][b][4 * q + e] + ((bias != nullptr && n < N) ? bias[n] : 0.f);
+            if (RELU) v = fmaxf(v, 0.f);
+            h[e] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
+          }
+          *reinterpret_cast<uint2*>(stage + (b * 32 + fr) * PITCH + nl * 2) =
               uint2{static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16), static_cast<unsigned>(h[2]) | (static_cast<unsigned>(h[3]) << 16)};
         }
+    // same wave wrote and reads: LDS operations of a wave are in order
+    const int piece = lane & 7, r0 = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + r0;
+      const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + piece * 8;
+      if (m < M && n < N) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + piece * 16);
+        unsigned short* dst = static_cast<unsigned short*>(Cout) + static_cast<long>(m) * ldc + n;
+        if (n + 8 <= N && (ldc & 7) == 0) *reinterpret_cast<u32x4*>(dst) = v;
+        else {
+          *reinterpret_cast<uint2*>(dst) = uint2{v[0], v[1]};            // N is a multiple of 4
+          if (n + 4 < N) *reinterpret_cast<uint2*>(dst + 4) = uint2{v[2], v[3]};
+        }
       }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = m0 + wm * 64 + b * 32 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
+          if (n >= N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[a][b][4 * q + e] + (bias != nullptr ? bias[n + e] : 0.f);
+            if (RELU) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<float4*>(static_cast<float*>(Cout) + static_cast<long>(m) * ldc + n) = float4{v[0], v[1], v[2], v[3]};
+        }
     }
   }
 }
