@@ -268,47 +268,53 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
     const bool shared = __any(near);     // wave-uniform: the two halves of the wave must take turns
 
     if (R > kMmaDenseRows) {
-      // ---- non-local level: corner by corner from global memory.  D layout: this lane holds channels
-      // tile*32 + 8*bq + 4*kg + (0..3) of query j; it needs all 4 points of the query: its own two and
-      // those of lane ^ 32.
+      // ---- non-local level: corner by corner from global memory.  Both lanes of a query walk all 4 points
+      // (the geometry of the other lane's points comes through a lane swap), each on its contiguous half of the
+      // 64 channels: four 16-byte loads per corner.  The half-rows are redistributed to the D layout (a lane
+      // holds channels tile*32 + 8*bq + 4*kg + (0..3)) with 16 swaps at the end of the level.
+      float tacc[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) tacc[i] = 0.f;
 #pragma unroll 1
-      for (int sp = 0; sp < 4; ++sp) {
-        {
-          const int side = sp >> 1;
-          MmaPoint g = (sp & 1) ? pt[l][1] : pt[l][0];
-          if (side) {
-            g.dhw = __shfl_xor(g.dhw, 32, 64);
-            g.ld = __shfl_xor(g.ld, 32, 64); g.lh = __shfl_xor(g.lh, 32, 64);
-            g.lw = __shfl_xor(g.lw, 32, 64); g.a = __shfl_xor(g.a, 32, 64);
-          }
-          if (g.dhw == 0x3fffffff) continue;
-          const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
+      for (int p4 = 0; p4 < 4; ++p4) {
+        MmaPoint g = (p4 & 1) ? pt[l][1] : pt[l][0];
+        MmaPoint o;
+        o.dhw = __shfl_xor(g.dhw, 32, 64);
+        o.ld = __shfl_xor(g.ld, 32, 64); o.lh = __shfl_xor(g.lh, 32, 64);
+        o.lw = __shfl_xor(g.lw, 32, 64); o.a = __shfl_xor(g.a, 32, 64);
+        if ((p4 >> 1) != kg) g = o;
+        if (g.dhw == 0x3fffffff) continue;
+        const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
 #pragma unroll 1
-          for (int k = 0; k < 8; ++k) {
-            const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
-            const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
-            if (static_cast<unsigned>(d) >= static_cast<unsigned>(D) || static_cast<unsigned>(h) >= static_cast<unsigned>(H) ||
-                static_cast<unsigned>(w) >= static_cast<unsigned>(W))
-              continue;
-            const float wv = g.a * ((dd ? g.ld : 1.f - g.ld) * (dh ? g.lh : 1.f - g.lh)) * (dw ? g.lw : 1.f - g.lw);
-            const long grow = order.start[l] + (static_cast<long>(d) * H + h) * W + w;
-            const VT* src = value + ((b * S + grow) * M + m) * C + 4 * kg;
+        for (int k = 0; k < 8; ++k) {
+          const int dd = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+          const int d = d0 + dd, h = h0 + dh, w = w0 + dw;
+          if (static_cast<unsigned>(d) >= static_cast<unsigned>(D) || static_cast<unsigned>(h) >= static_cast<unsigned>(H) ||
+              static_cast<unsigned>(w) >= static_cast<unsigned>(W))
+            continue;
+          const float wv = g.a * ((dd ? g.ld : 1.f - g.ld) * (dh ? g.lh : 1.f - g.lh)) * (dw ? g.lw : 1.f - g.lw);
+          const long grow = order.start[l] + (static_cast<long>(d) * H + h) * W + w;
+          const VT* src = value + ((b * S + grow) * M + m) * C + 32 * kg;
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile) {
+          for (int i = 0; i < 4; ++i) {
+            float vv[8];
+            Elem<VT>::unpack(reinterpret_cast<const u32x4*>(src)[i], vv);
 #pragma unroll
-              for (int bq = 0; bq < 4; ++bq) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(src + tile * 32 + 8 * bq);
-                const u32x4 r4{raw.x, raw.y, 0u, 0u};
-                float vv[8];
-                Elem<VT>::unpack(r4, vv);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  if (tile == 0) acc0[4 * bq + t] += wv * vv[t];
-                  else acc1[4 * bq + t] += wv * vv[t];
-                }
-              }
-            }
+            for (int e = 0; e < 8; ++e) tacc[8 * i + e] += wv * vv[e];
           }
+        }
+      }
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float keep = kg == 0 ? tacc[8 * bq + t] : tacc[8 * bq + 4 + t];          // stays in this lane
+          const float give = kg == 0 ? tacc[8 * bq + 4 + t] : tacc[8 * bq + t];          // belongs to the other one
+          const float got = __shfl_xor(give, 32, 64);
+          // lane kg = 0 holds channels 0..31: its own (8 bq + t) go to tile 0, the partner's (32 + 8 bq + t) to tile 1
+          // lane kg = 1 holds channels 32..63: the partner's (8 bq + 4 + t) go to tile 0, its own (32 + 8 bq + 4 + t) to tile 1
+          acc0[4 * bq + t] += kg == 0 ? keep : got;
+          acc1[4 * bq + t] += kg == 0 ? got : keep;
         }
       }
       have_pre = false;
