@@ -29,7 +29,12 @@ def test_captured_step_replays_reproduce_eager_gradients():
             if p_.dim() > 1 and float(p_.abs().max()) == 0:
                 torch.nn.init.xavier_uniform_(p_)
     model = model.cuda()
-    step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.bfloat16, graph=True)
+    # an explicit (eager) optimizer: the captured graph then holds forward + loss + backward only and replays
+    # leave the weights alone, so that every replay can be compared with the eager pass (the default on one GPU
+    # captures the AdamW update as well)
+    from transoar_amd.train_step import build_optimizer
+    step = TrainStep(model, build_criterion(cfg), cfg, optimizer=build_optimizer(model, cfg), amp_dtype=torch.bfloat16, graph=True)
+    assert not step.capture_optimizer
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.rand(2, 1, *cfg["volume_shape"], device="cuda", generator=g)
     targets = DenseTargets.from_list(synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda"),

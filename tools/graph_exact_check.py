@@ -30,7 +30,8 @@ for m in model.modules():
     if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
         m.dropout = 0.0
 model = model.cuda()
-step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.bfloat16, graph=True)
+from transoar_amd.train_step import build_optimizer  # noqa: E402
+step = TrainStep(model, build_criterion(cfg), cfg, optimizer=build_optimizer(model, cfg), amp_dtype=torch.bfloat16, graph=True)
 x = torch.rand(2, 1, *cfg["volume_shape"], device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234))
 targets = DenseTargets.from_list(synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda"), cfg["num_classes"], "cuda")
 params = {n: p for n, p in model.named_parameters() if p.requires_grad}

@@ -50,6 +50,12 @@ __device__ __forceinline__ unsigned short f32_to_f16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));
 }
 
+// LDS-only barrier: __syncthreads() carries a workgroup fence that also drains the outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0)), i.e. the prefetch of the next tiles, at every K step.  Here: LDS traffic done, then barrier.
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // block id -> (m tile, n tile): each XCD walks a contiguous eighth of the tiles, n fastest
 __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
   const long per = (n + 7) >> 3;
@@ -57,7 +63,7 @@ __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
   return swz < n ? swz : -1;
 }
 
-template <bool F16, bool OUT_F32, bool RELU>
+template <bool F16, bool OUT_F32, bool RELU, int KT_STATIC>
 __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles, int tiles_n) {
@@ -81,20 +87,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = s_row + 32 * i;
-    a_off[i] = (m0 + r) < M ? static_cast<unsigned>(m0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0xfffffff0u;
-    b_off[i] = (n0 + r) < N ? static_cast<unsigned>(n0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0xfffffff0u;
+    // a row past M / N gets an offset beyond any buffer (records < 2^31) that cannot wrap when the K offset is added
+    a_off[i] = (m0 + r) < M ? static_cast<unsigned>(m0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0x80000000u;
+    b_off[i] = (n0 + r) < N ? static_cast<unsigned>(n0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0x80000000u;
   }
-  u32x4 ra_regs[4], rb_regs[4];
-  auto load_tile = [&](int kt) {
-    const unsigned kbyte = static_cast<unsigned>(kt) * BK * 2u;
-    const bool in_k = kt * BK + s_piece * 8 < K;             // K is a multiple of 8 (checked on the host)
+  // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 waits in the other set
+  // (one tile ahead leaves the HBM latency exposed: a K step is only ~500 cycles of MFMA per wave)
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto load_tile = [&](int kt, u32x4 (&ra_regs)[4], u32x4 (&rb_regs)[4]) {
+    // the K offset rides in the instruction's scalar offset: no per-lane address arithmetic in the loop
+    const int kbyte = kt * BK * 2;
+    if ((kt + 1) * BK <= K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] + kbyte : 0xfffffff0u, 0, 0);
-      rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] + kbyte : 0xfffffff0u, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], kbyte, 0);
+        rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[i], kbyte, 0);
+      }
+    } else {                                                 // last, partial K tile: pieces past K read as zeros
+      const bool in_k = kt * BK + s_piece * 8 < K;           // K is a multiple of 8 (checked on the host)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] : 0x80000000u, kbyte, 0);
+        rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] : 0x80000000u, kbyte, 0);
+      }
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const u32x4 (&ra_regs)[4], const u32x4 (&rb_regs)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = s_row + 32 * i;
@@ -113,32 +131,83 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   const int KT = (K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int fr = lane & 31, kg = lane >> 5;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
+  // the lane's 32 bias values (n = n0 + wn*64 + a*32 + 8q + 4kg + e), requested before the K loop: eight
+  // 16-byte loads in flight together instead of 64 dependent scalar loads in the epilogue
+  float4 bv[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
+      bv[a][q] = (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  // fragment offsets inside an operand tile: loop invariant (row * 128 + swizzled piece * 16)
+  int fa_off[4][2], fb_off[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rm = wm * 64 + i * 32 + fr, rn = wn * 64 + i * 32 + fr, piece = 2 * ks + kg;
+      fa_off[ks][i] = rm * 128 + ((piece ^ (rm & 7)) << 4);
+      fb_off[ks][i] = rn * 128 + ((piece ^ (rn & 7)) << 4);
+    }
+  auto compute = [&](int stage) {
     const unsigned char* ta = lds[stage][0];
     const unsigned char* tb = lds[stage][1];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s16x8 fa[2], fb[2];
-      const int piece = 2 * ks + kg;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int rm = wm * 64 + i * 32 + fr, rn = wn * 64 + i * 32 + fr;
-        fa[i] = *reinterpret_cast<const s16x8*>(ta + rm * 128 + ((piece ^ (rm & 7)) << 4));
-        fb[i] = *reinterpret_cast<const s16x8*>(tb + rn * 128 + ((piece ^ (rn & 7)) << 4));
+        fa[i] = *reinterpret_cast<const s16x8*>(ta + fa_off[ks][i]);
+        fb[i] = *reinterpret_cast<const s16x8*>(tb + fb_off[ks][i]);
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = mfma<F16>(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
     }
-    if (kt + 1 < KT) store_tile(stage ^ 1);
-    __syncthreads();
+  };
+  if constexpr (KT_STATIC > 0) {
+    // K known at compile time (the token shapes: 384 and 1024): the K loop is straight-line code, so the
+    // compiler's wait counts are exact -- the ds_write of tile kt+1 waits for ITS loads only and leaves the
+    // loads of tile kt+2 in flight (across the loop back-edge of the generic form it drains them)
+    load_tile(0, ra0, rb0);
+    if (KT_STATIC > 1) load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    block_barrier();
+#pragma unroll
+    for (int kt = 0; kt < KT_STATIC; ++kt) {
+      if (kt & 1) {
+        if (kt + 2 < KT_STATIC) load_tile(kt + 2, ra1, rb1);
+        compute(1);
+        if (kt + 1 < KT_STATIC) store_tile(0, ra0, rb0);
+      } else {
+        if (kt + 2 < KT_STATIC) load_tile(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < KT_STATIC) store_tile(1, ra1, rb1);
+      }
+      block_barrier();
+    }
+  } else {
+  load_tile(0, ra0, rb0);
+  if (KT > 1) load_tile(1, ra1, rb1);
+  store_tile(0, ra0, rb0);
+  block_barrier();
+  for (int kt = 0; kt < KT; kt += 2) {
+    // even step: LDS stage 0 holds tile kt; set 0 is free, set 1 holds tile kt+1
+    if (kt + 2 < KT) load_tile(kt + 2, ra0, rb0);
+    compute(0);
+    if (kt + 1 < KT) store_tile(1, ra1, rb1);
+    block_barrier();
+    if (kt + 1 >= KT) break;
+    // odd step: stage 1 holds tile kt+1; set 1 is free, set 0 holds tile kt+2
+    if (kt + 3 < KT) load_tile(kt + 3, ra1, rb1);
+    compute(1);
+    if (kt + 2 < KT) store_tile(0, ra0, rb0);
+    block_barrier();
+  }
   }
 
   // epilogue.  A lane holds token m = .. + fr, outputs n = .. + 8 q + 4 kg + (0..3): stored straight from the
@@ -159,10 +228,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
         for (int q = 0; q < 4; ++q) {
           const int nl = a * 32 + 8 * q + 4 * kg;                       // column inside the wave tile
           unsigned short h[4];
+          const float bq4[4] = {bv[a][q].x, bv[a][q].y, bv[a][q].z, bv[a][q].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn * 64 + nl + e;
-            float v = acc[a][b][4 * q + e] + ((bias != nullptr && n < N) ? bias[n] : 0.f);
+            float v = acc[a][b][4 * q + e] + bq4[e];
             if (RELU) v = fmaxf(v, 0.f);
             h[e] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
           }
@@ -197,9 +266,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
           const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
           if (n >= N) continue;
           float v[4];
+          const float bq4[4] = {bv[a][q].x, bv[a][q].y, bv[a][q].z, bv[a][q].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = acc[a][b][4 * q + e] + (bias != nullptr ? bias[n + e] : 0.f);
+            v[e] = acc[a][b][4 * q + e] + bq4[e];
             if (RELU) v[e] = fmaxf(v[e], 0.f);
           }
           *reinterpret_cast<float4*>(static_cast<float*>(Cout) + static_cast<long>(m) * ldc + n) = float4{v[0], v[1], v[2], v[3]};
@@ -216,10 +286,20 @@ int launch(const void* A, const void* B, const float* bias, void* C, int M, int 
   const dim3 grid(static_cast<unsigned>(((n_tiles + 7) / 8) * 8));
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
-  if (relu)
-    hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, true>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, ldc, n_tiles, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, false>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, ldc, n_tiles, tiles_n);
+#define TRANSOAR_GEMM_LAUNCH(R, KTS)                                                                                   \
+  hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
+                     ldc, n_tiles, tiles_n)
+  const int kts = K == 384 ? 6 : (K == 1024 ? 16 : 0);
+  if (relu) {
+    if (kts == 6) TRANSOAR_GEMM_LAUNCH(true, 6);
+    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(true, 16);
+    else TRANSOAR_GEMM_LAUNCH(true, 0);
+  } else {
+    if (kts == 6) TRANSOAR_GEMM_LAUNCH(false, 6);
+    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(false, 16);
+    else TRANSOAR_GEMM_LAUNCH(false, 0);
+  }
+#undef TRANSOAR_GEMM_LAUNCH
   return static_cast<int>(hipGetLastError());
 }
 
@@ -231,7 +311,7 @@ extern "C" int transoar_gemm_nt(const void* A, const void* B, const float* bias,
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7) || (ldc & 3))
     return TRANSOAR_GEMM_ERR_DIM;
   if (static_cast<long>(N) * ldb * 2 >= 0x7ffffff0L || static_cast<long>(M) * lda * 2 >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;
-  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15u) return TRANSOAR_GEMM_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15u) return TRANSOAR_GEMM_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const bool f16 = in_dtype == TRANSOAR_GEMM_F16;
   if (in_dtype != TRANSOAR_GEMM_BF16 && !f16) return TRANSOAR_GEMM_ERR_DTYPE;

@@ -1,10 +1,13 @@
 """nn.Linear over the flattened feature pyramid (10^5 tokens per volume).
 
-Forward and input gradient are plain NT GEMMs.  Two implementations: hipBLASLt (default: 0.17 / 0.27 / 0.23 ms on
-the 234 000-token shapes 384->384 / 384->1024 / 1024->384) and the hand-written bf16 MFMA GEMM of csrc/gemm.hip
-(TRANSOAR_HIP_GEMM=1 or token_linear.USE_HIP_GEMM = True: x (T, K) . W (N, K)^T with the bias in the epilogue;
-dX = dY . W is the same product with W^T as the (N, K)-shaped operand; 0.22 / 0.55 / 0.37 ms -- its one-tile-ahead
-register prefetch does not cover the HBM latency at K = 384).  The weight gradient
+Forward and input gradient are plain NT GEMMs (x (T, K) . W (N, K)^T with the bias in the epilogue; dX = dY . W is
+the same product with W^T as the (N, K)-shaped operand).  Two implementations, chosen per shape by measured time at
+the 234 000-token shapes (profiles/r02_gemm_bench.jsonl): the hand-written bf16 MFMA GEMM of csrc/gemm.hip for the
+K = N = 384 products -- value_proj, output_proj, the stacked sampling_offsets|attention_weights projection and
+their data gradients: 0.15-0.16 ms = hipBLASLt's 0.16 ms -- and hipBLASLt for the FFN shapes 384 -> 1024 -> 384
+(0.27 / 0.22 ms against 0.37 / 0.27 ms).  TRANSOAR_HIP_GEMM=1 / 0 forces one of them everywhere.
+
+The weight gradient
 dW = dY^T X contracts over the TOKEN axis (K = 234 000 at batch 2) into a tile
 of at most 1024 x 384: hipBLASLt covers that with a few dozen workgroups on a
 256-CU part (0.5-0.9 ms, 40-230 TFLOP/s measured).  Here the token axis is cut
@@ -24,7 +27,16 @@ from . import gemm
 
 MIN_TOKENS = 32768          # below this the stock path is as fast
 LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
-USE_HIP_GEMM = bool(os.environ.get("TRANSOAR_HIP_GEMM"))
+USE_HIP_GEMM = {"1": True, "0": False}.get(os.environ.get("TRANSOAR_HIP_GEMM", ""), None)     # None: per shape
+
+
+def _hip_gemm(x2, w):
+    """Hand-written kernel for this product?  (x2 (T, K), w (N, K))"""
+    if not gemm.usable(x2, w):
+        return False
+    if USE_HIP_GEMM is not None:
+        return USE_HIP_GEMM
+    return x2.shape[1] == 384 and w.shape[0] == 384
 
 
 def _chunks(tokens, n_out, n_in):
@@ -56,7 +68,7 @@ class _TokenLinear(torch.autograd.Function):
         ctx.in_dtype, ctx.has_bias = x.dtype, bias is not None
         global LAST_PATH
         x2 = xb.reshape(-1, xb.shape[-1])
-        if USE_HIP_GEMM and gemm.usable(x2, wb):
+        if _hip_gemm(x2, wb):
             LAST_PATH = "hip-gemm"
             # the bias is added in fp32 before the single rounding to bf16 (F.linear rounds the bias to bf16 first)
             return gemm.linear_nt(x2, wb, bias).view(*xb.shape[:-1], wb.shape[0])
@@ -74,8 +86,8 @@ class _TokenLinear(torch.autograd.Function):
         gx = gw = gb = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
-                wt = wb.t().contiguous() if USE_HIP_GEMM else None     # (K, N): dX = dY . W as an NT product
-                gx = gemm.linear_nt(gy2, wt) if USE_HIP_GEMM and gemm.usable(gy2, wt) else torch.mm(gy2, wb)
+                wt = wb.t().contiguous()                   # (K, N): dX = dY . W as an NT product
+                gx = gemm.linear_nt(gy2, wt) if _hip_gemm(gy2, wt) else torch.mm(gy2, wb)
                 gx = gx.view(xb.shape).to(ctx.in_dtype)
             if ctx.needs_input_grad[1]:
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
