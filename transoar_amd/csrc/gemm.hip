@@ -28,9 +28,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kThreads = 256;
-constexpr int kTileBytes = 128 * BK * 2;                 // one operand tile: 16 KiB
+constexpr int BM = 128, BK = 64;
+constexpr int kATileBytes = BM * BK * 2;                  // 16 KiB; the B tile is (64 * WN) rows
 
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
@@ -63,16 +62,18 @@ __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
   return swz < n ? swz : -1;
 }
 
-template <bool F16, bool OUT_F32, bool RELU, int KT_STATIC>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
+template <bool F16, bool OUT_F32, bool RELU, int KT_STATIC, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kTileBytes];     // [stage][A|B]
+  constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (2 or 4), 2 along M
+  constexpr int kStageBytes = kATileBytes + BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][kStageBytes];      // [stage]: A tile, then B tile
   const long t = xcd_contiguous(blockIdx.x, n_tiles);
   if (t < 0) return;
   const int tm = static_cast<int>(t / tiles_n), tn = static_cast<int>(t % tiles_n);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;                   // wave's 64 x 64 quadrant of the block tile
+  const int wm = wave / WN, wn = wave % WN;                  // wave's 64 x 64 part of the block tile
   const int m0 = tm * BM, n0 = tn * BN;
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
@@ -82,43 +83,50 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
 
   // staging: thread -> (row, 16-byte piece) x 4 per operand.  The row's pieces past K read as zeros (offset
   // clamp below), rows past M / N are beyond the buffer: zeros as well.
-  const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + 32 i
-  unsigned a_off[4], b_off[4];
+  constexpr int RPP = kThreads / 8;                          // rows covered per pass of the block
+  constexpr int NA = BM / RPP, NB = BN / RPP;                // passes per operand tile: (4, 4) or (2, 4)
+  const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + RPP i
+  unsigned a_off[NA], b_off[NB];
+  // a row past M / N gets an offset beyond any buffer (records < 2^31) that cannot wrap when the K offset is added
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = s_row + 32 * i;
-    // a row past M / N gets an offset beyond any buffer (records < 2^31) that cannot wrap when the K offset is added
+  for (int i = 0; i < NA; ++i) {
+    const int r = s_row + RPP * i;
     a_off[i] = (m0 + r) < M ? static_cast<unsigned>(m0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0x80000000u;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = s_row + RPP * i;
     b_off[i] = (n0 + r) < N ? static_cast<unsigned>(n0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0x80000000u;
   }
   // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 waits in the other set
   // (one tile ahead leaves the HBM latency exposed: a K step is only ~500 cycles of MFMA per wave)
-  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-  auto load_tile = [&](int kt, u32x4 (&ra_regs)[4], u32x4 (&rb_regs)[4]) {
+  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  auto load_tile = [&](int kt, u32x4 (&ra_regs)[NA], u32x4 (&rb_regs)[NB]) {
     // the K offset rides in the instruction's scalar offset: no per-lane address arithmetic in the loop
     const int kbyte = kt * BK * 2;
     if ((kt + 1) * BK <= K) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], kbyte, 0);
-        rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[i], kbyte, 0);
-      }
+      for (int i = 0; i < NA; ++i) ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], kbyte, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[i], kbyte, 0);
     } else {                                                 // last, partial K tile: pieces past K read as zeros
       const bool in_k = kt * BK + s_piece * 8 < K;           // K is a multiple of 8 (checked on the host)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] : 0x80000000u, kbyte, 0);
-        rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] : 0x80000000u, kbyte, 0);
-      }
+      for (int i = 0; i < NA; ++i) ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] : 0x80000000u, kbyte, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] : 0x80000000u, kbyte, 0);
     }
   };
-  auto store_tile = [&](int stage, const u32x4 (&ra_regs)[4], const u32x4 (&rb_regs)[4]) {
+  auto store_tile = [&](int stage, const u32x4 (&ra_regs)[NA], const u32x4 (&rb_regs)[NB]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = s_row + 32 * i;
-      const int off = r * 128 + ((s_piece ^ (r & 7)) << 4);
-      *reinterpret_cast<u32x4*>(&lds[stage][0][off]) = ra_regs[i];
-      *reinterpret_cast<u32x4*>(&lds[stage][1][off]) = rb_regs[i];
+    for (int i = 0; i < NA; ++i) {
+      const int r = s_row + RPP * i;
+      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ (r & 7)) << 4)]) = ra_regs[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = s_row + RPP * i;
+      *reinterpret_cast<u32x4*>(&lds[stage][kATileBytes + r * 128 + ((s_piece ^ (r & 7)) << 4)]) = rb_regs[i];
     }
   };
 
@@ -153,8 +161,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
       fb_off[ks][i] = rn * 128 + ((piece ^ (rn & 7)) << 4);
     }
   auto compute = [&](int stage) {
-    const unsigned char* ta = lds[stage][0];
-    const unsigned char* tb = lds[stage][1];
+    const unsigned char* ta = lds[stage];
+    const unsigned char* tb = lds[stage] + kATileBytes;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s16x8 fa[2], fb[2];
@@ -216,8 +224,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
   // whole rows: 16 bytes per lane, 8 (4 for fp32) consecutive rows of 128 (256) contiguous bytes per store.
   constexpr int ELT = OUT_F32 ? 4 : 2;
   constexpr int PITCH = 64 * ELT + 16;
-  unsigned char* stage = &lds[0][0][0] + wave * (64 * PITCH);          // 4 x 64 x 272 = 68 KiB would not fit for fp32:
-  static_assert(4 * 64 * (64 * 2 + 16) <= 4 * kTileBytes, "bf16 staging fits");
+  unsigned char* stage = &lds[0][0] + wave * (64 * PITCH);
+  static_assert(2 * WN * 64 * (64 * 2 + 16) <= 2 * kStageBytes, "bf16 staging fits");
   // (the main loop's last barrier has passed: every wave is done reading the operand tiles)
   if constexpr (!OUT_F32) {
 #pragma unroll
@@ -281,14 +289,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
 template <bool F16, bool OUT_F32>
 int launch(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc, int relu,
            hipStream_t st) {
+  // the 128 x 256 tile (8 waves, half the re-reads of the activation rows) measured SLOWER on 234000 x 384 -> 1024
+  // (0.41 vs 0.38 ms: one 96-KiB block per CU) -- kept as a template instance, not selected
+  const bool wide = false;
+  const int BN = wide ? 256 : 128;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const long n_tiles = static_cast<long>(tiles_m) * tiles_n;
   const dim3 grid(static_cast<unsigned>(((n_tiles + 7) / 8) * 8));
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
-#define TRANSOAR_GEMM_LAUNCH(R, KTS)                                                                                   \
-  hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS>), grid, dim3(kThreads), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
-                     ldc, n_tiles, tiles_n)
+#define TRANSOAR_GEMM_LAUNCH(R, KTS)                                                                                        \
+  do {                                                                                                                      \
+    if (wide)                                                                                                               \
+      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS, 4>), grid, dim3(512), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
+                         ldc, n_tiles, tiles_n);                                                                            \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS, 2>), grid, dim3(256), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
+                         ldc, n_tiles, tiles_n);                                                                            \
+  } while (0)
   const int kts = K == 384 ? 6 : (K == 1024 ? 16 : 0);
   if (relu) {
     if (kts == 6) TRANSOAR_GEMM_LAUNCH(true, 6);
