@@ -63,3 +63,40 @@ def test_layout_kernels_roundtrip():
     assert cl.is_contiguous(memory_format=torch.channels_last_3d) and torch.equal(cl, x)
     back = to_ncdhw(cl)
     assert back.is_contiguous() and torch.equal(back, x)
+
+
+def _gpu_relerr(a, b):
+    return float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-30)
+
+
+# The flagship step's first layers at their real size (batch 2 of 160x160x256, config.py _BACKBONE): stem 1->24,
+# 24->24 at full resolution, the first strided stage 24->48.  Class defaults (min_voxels, which gradients are
+# hand-written) stay as the training step uses them.
+@pytest.mark.parametrize("case", [(2, 1, 24, 160, 160, 256, 1), (2, 24, 24, 160, 160, 256, 1),
+                                  (2, 24, 48, 160, 160, 256, 2)])
+def test_conv3d_k3_flagship_layer_shapes(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd.conv3d import Conv3dK3, _Conv3dK3
+    Conv3dK3.min_voxels = 1 << 20
+    _Conv3dK3.hip_wgrad, _Conv3dK3.hip_dgrad_strided = False, False      # class defaults
+    n, ci, co, d, h, w, s = case
+    torch.manual_seed(ci + co)
+    conv = Conv3dK3(ci, co, 3, stride=s, padding=1, bias=False).cuda()
+    x = torch.randn(n, ci, d, h, w, device="cuda").to(torch.bfloat16)
+    if ci != 1:
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+    x.requires_grad_(ci != 1)
+    y = conv(x)
+    assert y.dtype == torch.bfloat16
+    xr = x.detach().float().requires_grad_(ci != 1)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    yr = F.conv3d(xr, wr, None, stride=s, padding=1)
+    assert _gpu_relerr(y, yr) <= 2.0 ** -7
+    g = torch.randn(yr.shape, device="cuda").to(torch.bfloat16)
+    y.backward(g)
+    yr.backward(g.float())
+    # 13e6-term fp32 sums of bf16 products against fp32 sums of fp32 products, different summation orders
+    assert _gpu_relerr(conv.weight.grad, wr.grad) <= 5e-3
+    if ci != 1:
+        assert _gpu_relerr(x.grad, xr.grad) <= 2.0 ** -7

@@ -38,3 +38,30 @@ def test_instnorm_relu(shape, relu):
     assert relerr(x.grad, xr.grad) <= 2e-2      # bf16 dx; the relu mask can flip on rounding ties
     assert relerr(gamma.grad, gr.grad) <= 1e-2
     assert relerr(beta.grad, br.grad) <= 1e-2
+
+
+def test_instnorm_relu_flagship_stem_shape():
+    """The largest InstanceNorm of the step: batch 2 x 24 channels x 160x160x256 (6.5e6 voxels per instance)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd.instnorm import instance_norm_relu, supported
+    torch.manual_seed(24)
+    shape = (2, 24, 160, 160, 256)
+    x = (torch.randn(shape, device="cuda") * 2 + 0.5).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last_3d).requires_grad_()
+    assert supported(x, 24)
+    gamma = (1 + 0.2 * torch.randn(24, device="cuda")).requires_grad_()
+    beta = (0.3 * torch.randn(24, device="cuda")).requires_grad_()
+    y = instance_norm_relu(x, gamma, beta, 1e-5, True)
+    xr = x.detach().float().requires_grad_()
+    gr, br = gamma.detach().clone().requires_grad_(), beta.detach().clone().requires_grad_()
+    yr = F.relu(F.instance_norm(xr, weight=gr, bias=br, eps=1e-5))
+    err = lambda a, b: float((a.float() - b.float()).abs().max()) / float(b.float().abs().max())
+    assert err(y, yr) <= 2.0 ** -7
+    g = torch.randn(shape, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    y.backward(g)
+    yr.backward(g.float())
+    assert err(x.grad, xr.grad) <= 2e-2
+    # per-channel sums over 13e6 voxels: fp32 accumulation order differs
+    assert err(gamma.grad, gr.grad) <= 1e-2
+    assert err(beta.grad, br.grad) <= 1e-2
