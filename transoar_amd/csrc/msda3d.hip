@@ -15,6 +15,7 @@
 #include "msda3d_brick.hpp"
 #include "msda3d_mma.hpp"
 #include "msda3d_tile.hpp"
+#include "msda3d_cells_mma.hpp"
 #include "msda3d_gather.hpp"
 #include "msda3d_generic.hpp"
 #include "msda3d_scatter.hpp"
@@ -435,17 +436,35 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, cst);
         TRANSOAR_CHECK_HIP(zero_async(scratch, sizeof(float) * scratch_elems, cst));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
-        hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
-                           go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl_d,
-                           r_order_d);
+        bool mma = false;
+        if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
+        if (mma) {
+          if constexpr (sizeof(VT) == 2)       // 16 sorted points per MFMA K-step (msda3d_cells_mma.hpp)
+            hipLaunchKernelGGL((msda3d_bwd_value_cells_mma<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0,
+                               cst, go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
+                               cl_d, r_order_d);
+        } else {
+          hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
+                             go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M, cl_d,
+                             r_order_d);
+        }
       }
       if (side != nullptr) TRANSOAR_CHECK_HIP(hipEventRecord(side->join, side->stream));
       ProfScope prof(TRANSOAR_PROF_VALUE_TILE, st);
       if (fine_bricks > 0) {
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
-        hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
-                           count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
-                           d.S, d.M, fine_bricks, n_wg, r_order_d);
+        bool mma = false;
+        if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
+        if (mma) {
+          if constexpr (sizeof(VT) == 2)
+            hipLaunchKernelGGL((msda3d_bwd_value_tile_mma<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st,
+                               go, count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
+                               d.S, d.M, fine_bricks, n_wg, r_order_d);
+        } else {
+          hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
+                             count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
+                             d.S, d.M, fine_bricks, n_wg, r_order_d);
+        }
       }
       if (side != nullptr) TRANSOAR_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
       if (coarse_levels > 0) {
