@@ -72,6 +72,18 @@ int transoar_relu_dropout_backward(const void* gy, const void* y, float keep_sca
                                    void* hip_stream);
 int transoar_add_layernorm_partial_rows(void);
 
+/* Head of MSDeformAttn.forward (transoar/models/ops/modules/ms_deform_attn.py:114-128): from the stacked
+ * projection proj (tokens, 4*M*L*P) bf16 = [sampling_offsets (M, L, P, 3) | attention_weights logits (M, L*P)],
+ *     loc  (tokens, M, L, P, 3) fp32 = ref (ref_rows, L, 3)[token % ref_rows] + bf16(offset / bf16(W_l, H_l, D_l))
+ *          (ref_rows = tokens, or the tokens of one batch element when the reference points are shared)
+ *     attn (tokens, M, L, P)    fp32 = softmax over L*P of the logits
+ * with the rounding points of the eager chain under bf16 autocast.  shapes (L, 3) int64 [D, H, W] on the device.
+ * backward: g_proj (tokens, 4*M*L*P) bf16 from the gradients of loc and attn (ref receives none).  L*P <= 256. */
+int transoar_sampling_head_forward(const void* proj, const float* ref, long ref_rows, const long* shapes, float* loc,
+                                   float* attn, long tokens, int M, int L, int P, void* hip_stream);
+int transoar_sampling_head_backward(const float* g_loc, const float* g_attn, const float* attn, const long* shapes,
+                                    void* g_proj, long tokens, int M, int L, int P, void* hip_stream);
+
 int transoar_tokens_abi_version(void);
 
 #ifdef __cplusplus

@@ -117,3 +117,40 @@ def test_dropout_inside_add_layernorm_and_relu_dropout():
     drop = torch.nn.Dropout(0.1).eval()
     assert torch.equal(tokens.relu_dropout(h0, drop), torch.relu(h0))
 
+
+
+@pytest.mark.parametrize("geom", [(2, 6, 4, 4, ((5, 5, 8), (3, 3, 4), (2, 2, 2), (1, 1, 2))), (1, 6, 3, 4, ((4, 4, 4), (2, 2, 2), (1, 1, 1))),
+                                  (2, 8, 2, 2, ((3, 4, 5), (2, 2, 3)))])
+@pytest.mark.parametrize("shared_ref", [True, False])
+def test_sampling_head_matches_eager_chain(geom, shared_ref):
+    """The fused MSDeformAttn head (offsets -> locations, logits -> softmax) against the eager autocast chain of
+    ms_deform_attn.py:114-128: same rounding points, so forward agrees to fp32 rounding of the softmax and the
+    gradient of the projection to one bf16 ulp of the largest entry."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from transoar_amd import tokens
+    n, m, lv, pt, shapes = geom
+    torch.manual_seed(n * 100 + m)
+    lq = sum(d * h * w for d, h, w in shapes)
+    spatial = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    proj = (torch.randn(n, lq, 4 * m * lv * pt, device="cuda") * 1.5).to(torch.bfloat16).requires_grad_()
+    ref = torch.rand(1 if shared_ref else n, lq, lv, 3, device="cuda")
+    assert tokens.sampling_head_usable(proj, ref, spatial, m, lv, pt)
+    loc, attn = tokens.sampling_head(proj, ref, spatial, m, lv, pt)
+    g_loc, g_attn = torch.randn_like(loc), torch.randn_like(attn)
+    (g_proj,) = torch.autograd.grad([loc, attn], [proj], [g_loc, g_attn])
+
+    p2 = proj.detach().clone().requires_grad_()
+    n_off = m * lv * pt * 3
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        offsets = p2[..., :n_off].unflatten(-1, (m, lv, pt, 3))
+        w = F.softmax(p2[..., n_off:].unflatten(-1, (m, lv * pt)), dim=-1).view(n, lq, m, lv, pt)
+        whd = spatial.flip(-1).to(offsets.dtype)
+        loc_ref = ref[:, :, None, :, None, :] + offsets / whd[None, None, None, :, None, :]
+    assert loc_ref.dtype == torch.float32 and w.dtype == torch.float32
+    (g_ref,) = torch.autograd.grad([loc_ref, w], [p2], [g_loc, g_attn])
+    assert torch.equal(loc, loc_ref.expand_as(loc))
+    assert float((attn - w).abs().max()) <= 1e-6
+    err = float((g_proj.float() - g_ref.float()).abs().max())
+    assert err <= 2.0 ** -7 * float(g_ref.float().abs().max()), err

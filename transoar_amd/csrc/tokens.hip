@@ -241,6 +241,81 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd(const uint4* __restrict_
   gh[i] = uint4{out[0], out[1], out[2], out[3]};
 }
 
+// ---------------------------------------------------------------------------
+// Head of MSDeformAttn (ms_deform_attn.py:114-128 of the reference) on the stacked projection
+// proj (T, M*G*3 + M*G) bf16 = [sampling offsets (M, L, P, 3) | attention logits (M, L*P)], G = L*P:
+//     loc  (T, M, L, P, 3) fp32 = ref (T, L, 3) + bf16(off / bf16(W_l, H_l, D_l))
+//     attn (T, M, G)      fp32 = softmax over G of the logits (fp32 arithmetic)
+// -- the rounding points of the eager chain under autocast (bf16 division, fp32 add and softmax).  One thread
+// per (token, head, level*point); the G logits of a head meet in LDS.  Backward: the gradient of proj in bf16.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_round(float f) { return __uint_as_float(f32_to_bf16_bits(f) << 16); }
+
+__global__ __launch_bounds__(256) void sampling_head_fwd(const unsigned short* __restrict__ proj,
+                                                         const float* __restrict__ ref, const long* __restrict__ shapes,
+                                                         float* __restrict__ loc, float* __restrict__ attn, int M, int L,
+                                                         int P, long n_elem, long ref_rows) {
+  __shared__ float sh[256];
+  const int G = L * P, cols = 4 * M * G;
+  const long e = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = e < n_elem;
+  const long ec = live ? e : n_elem - 1;
+  const int g = static_cast<int>(ec % G);
+  const long tm = ec / G;
+  const int m = static_cast<int>(tm % M);
+  const long t = tm / M;
+  const unsigned short* row = proj + t * cols;
+  const float logit = __uint_as_float(static_cast<unsigned>(row[3 * M * G + m * G + g]) << 16);
+  sh[threadIdx.x] = logit;
+  __syncthreads();
+  const float* grp = sh + (threadIdx.x - g);
+  float mx = grp[0];
+  for (int i = 1; i < G; ++i) mx = fmaxf(mx, grp[i]);
+  float sum = 0.f;
+  for (int i = 0; i < G; ++i) sum += __expf(grp[i] - mx);
+  if (!live) return;
+  attn[e] = __expf(logit - mx) / sum;
+  const int l = g / P;
+  const unsigned short* o = row + (m * G + g) * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float size = bf16_round(static_cast<float>(shapes[l * 3 + 2 - k]));       // (W, H, D) for (x, y, z)
+    const float off = __uint_as_float(static_cast<unsigned>(o[k]) << 16);
+    loc[e * 3 + k] = ref[((t % ref_rows) * L + l) * 3 + k] + bf16_round(off / size);
+  }
+}
+
+__global__ __launch_bounds__(256) void sampling_head_bwd(const float* __restrict__ g_loc, const float* __restrict__ g_attn,
+                                                         const float* __restrict__ attn, const long* __restrict__ shapes,
+                                                         unsigned short* __restrict__ g_proj, int M, int L, int P,
+                                                         long n_elem) {
+  __shared__ float sh[256];
+  const int G = L * P, cols = 4 * M * G;
+  const long e = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = e < n_elem;
+  const long ec = live ? e : n_elem - 1;
+  const int g = static_cast<int>(ec % G);
+  const long tm = ec / G;
+  const int m = static_cast<int>(tm % M);
+  const long t = tm / M;
+  const float a = attn[ec], ga = g_attn[ec];
+  sh[threadIdx.x] = a * ga;
+  __syncthreads();
+  const float* grp = sh + (threadIdx.x - g);
+  float dot = 0.f;
+  for (int i = 0; i < G; ++i) dot += grp[i];
+  if (!live) return;
+  unsigned short* row = g_proj + t * cols;
+  row[3 * M * G + m * G + g] = static_cast<unsigned short>(f32_to_bf16_bits(a * (ga - dot)));
+  const int l = g / P;
+  unsigned short* o = row + (m * G + g) * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float size = bf16_round(static_cast<float>(shapes[l * 3 + 2 - k]));
+    o[k] = static_cast<unsigned short>(f32_to_bf16_bits(bf16_round(g_loc[e * 3 + k]) / size));
+  }
+}
+
 }  // namespace
 
 #define TOK_DISPATCH(K_, BODY) \
@@ -330,5 +405,31 @@ extern "C" int transoar_relu_dropout_backward(const void* gy, const void* y, flo
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_sampling_head_forward(const void* proj, const float* ref, long ref_rows, const long* shapes,
+                                             float* loc, float* attn, long tokens, int M, int L, int P,
+                                             void* hip_stream) {
+  if (!proj || !ref || !shapes || !loc || !attn) return TRANSOAR_TOK_ERR_NULL;
+  if (tokens <= 0 || M <= 0 || L <= 0 || P <= 0 || L * P > 256 || ref_rows <= 0 || tokens % ref_rows) return TRANSOAR_TOK_ERR_DIM;
+  const int G = L * P, threads = (256 / G) * G;
+  const long n = tokens * M * G;
+  hipLaunchKernelGGL(sampling_head_fwd, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(proj), ref, shapes, loc, attn,
+                     M, L, P, n, ref_rows);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_sampling_head_backward(const float* g_loc, const float* g_attn, const float* attn,
+                                              const long* shapes, void* g_proj, long tokens, int M, int L, int P,
+                                              void* hip_stream) {
+  if (!g_loc || !g_attn || !attn || !shapes || !g_proj) return TRANSOAR_TOK_ERR_NULL;
+  if (tokens <= 0 || M <= 0 || L <= 0 || P <= 0 || L * P > 256) return TRANSOAR_TOK_ERR_DIM;
+  const int G = L * P, threads = (256 / G) * G;
+  const long n = tokens * M * G;
+  hipLaunchKernelGGL(sampling_head_bwd, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
+                     static_cast<hipStream_t>(hip_stream), g_loc, g_attn, attn, shapes, static_cast<unsigned short*>(g_proj),
+                     M, L, P, n);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 2; }
+extern "C" int transoar_tokens_abi_version(void) { return 3; }

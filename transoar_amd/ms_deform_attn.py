@@ -26,6 +26,7 @@ from torch.autograd.function import once_differentiable
 
 from . import msda as MSDA
 from .token_linear import token_linear
+from .tokens import sampling_head as _sampling_head, sampling_head_usable as _sampling_head_usable
 
 _debug_core = None
 
@@ -137,12 +138,15 @@ class MSDeformAttn(nn.Module):
         n_off = self.sampling_offsets.out_features
         proj = token_linear(query, torch.cat((self.sampling_offsets.weight, self.attention_weights.weight)),
                             torch.cat((self.sampling_offsets.bias, self.attention_weights.bias)))
-        offsets = proj[..., :n_off].unflatten(-1, (m, lv, pt, 3))
-        weights = F.softmax(proj[..., n_off:].unflatten(-1, (m, lv * pt)), dim=-1)
-        weights = weights.view(n, lq, m, lv, pt)
-        # offsets are in voxels of their level: divide by (W,H,D)
-        whd = input_spatial_shapes.flip(-1).to(offsets.dtype)
-        locations = reference_points[:, :, None, :, None, :] + offsets / whd[None, None, None, :, None, :]
+        if self.use_cuda and _sampling_head_usable(proj, reference_points, input_spatial_shapes, m, lv, pt):
+            locations, weights = _sampling_head(proj, reference_points, input_spatial_shapes, m, lv, pt)
+        else:
+            offsets = proj[..., :n_off].unflatten(-1, (m, lv, pt, 3))
+            weights = F.softmax(proj[..., n_off:].unflatten(-1, (m, lv * pt)), dim=-1)
+            weights = weights.view(n, lq, m, lv, pt)
+            # offsets are in voxels of their level: divide by (W,H,D)
+            whd = input_spatial_shapes.flip(-1).to(offsets.dtype)
+            locations = reference_points[:, :, None, :, None, :] + offsets / whd[None, None, None, :, None, :]
 
         if self.use_cuda:
             sampled = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,

@@ -32,8 +32,12 @@ def _load():
     lib.transoar_relu_dropout_backward.restype = i
     lib.transoar_relu_dropout_backward.argtypes = [p, p, f, p, lg, p]
     lib.transoar_add_layernorm_partial_rows.restype = i
+    lib.transoar_sampling_head_forward.restype = i
+    lib.transoar_sampling_head_forward.argtypes = [p, p, lg, p, p, p, lg, i, i, i, p]
+    lib.transoar_sampling_head_backward.restype = i
+    lib.transoar_sampling_head_backward.argtypes = [p, p, p, p, p, lg, i, i, i, p]
     lib.transoar_tokens_abi_version.restype = i
-    if lib.transoar_tokens_abi_version() != 2:
+    if lib.transoar_tokens_abi_version() != 3:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -165,3 +169,53 @@ def relu_dropout(h, dropout):
     active = dropout.training and dropout.p > 0.0
     keep = dropout_mask(h, dropout.p) if active else None
     return _ReluDropout.apply(h, keep, 1.0 / (1.0 - dropout.p) if active else 1.0)
+
+
+class _SamplingHead(torch.autograd.Function):
+    """(proj bf16 (N, Lq, 4*M*L*P), reference_points fp32 (N or 1, Lq, L, 3), shapes int64 (L, 3)) ->
+    (locations fp32 (N, Lq, M, L, P, 3), attention weights fp32 (N, Lq, M, L, P))"""
+
+    @staticmethod
+    def forward(ctx, proj, reference_points, shapes, m, lv, pt):
+        n, lq, _ = proj.shape
+        loc = torch.empty((n, lq, m, lv, pt, 3), dtype=torch.float32, device=proj.device)
+        attn = torch.empty((n, lq, m, lv, pt), dtype=torch.float32, device=proj.device)
+        with torch.cuda.device(proj.device):
+            rc = lib.transoar_sampling_head_forward(proj.data_ptr(), reference_points.data_ptr(),
+                                                    reference_points.shape[0] * lq, shapes.data_ptr(),
+                                                    loc.data_ptr(), attn.data_ptr(), n * lq, m, lv, pt,
+                                                    torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_sampling_head_forward failed with code %d" % rc)
+        ctx.save_for_backward(attn, shapes)
+        ctx.dims = (m, lv, pt, proj.shape)
+        return loc, attn
+
+    @staticmethod
+    def backward(ctx, g_loc, g_attn):
+        attn, shapes = ctx.saved_tensors
+        m, lv, pt, shape = ctx.dims
+        g_loc, g_attn = g_loc.contiguous(), g_attn.contiguous()
+        g_proj = torch.empty(shape, dtype=torch.bfloat16, device=attn.device)
+        with torch.cuda.device(attn.device):
+            rc = lib.transoar_sampling_head_backward(g_loc.data_ptr(), g_attn.data_ptr(), attn.data_ptr(), shapes.data_ptr(),
+                                                     g_proj.data_ptr(), shape[0] * shape[1], m, lv, pt,
+                                                     torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_sampling_head_backward failed with code %d" % rc)
+        return g_proj, None, None, None, None, None
+
+
+def sampling_head_usable(proj, reference_points, shapes, m, lv, pt):
+    return (proj.is_cuda and proj.dtype == torch.bfloat16 and proj.is_contiguous() and proj.dim() == 3
+            and proj.shape[-1] == 4 * m * lv * pt and lv * pt <= 256
+            and reference_points.dtype == torch.float32 and reference_points.is_contiguous()
+            and not reference_points.requires_grad and tuple(reference_points.shape[1:]) == (proj.shape[1], lv, 3)
+            and reference_points.shape[0] in (1, proj.shape[0])
+            and shapes.dtype == torch.int64 and shapes.is_cuda and shapes.is_contiguous())
+
+
+def sampling_head(proj, reference_points, shapes, m, lv, pt):
+    """Sampling locations and attention weights of MSDeformAttn from the stacked projection, one kernel each way
+    (instead of slice, divide, add, softmax and their backward chain with its concatenation)."""
+    return _SamplingHead.apply(proj, reference_points, shapes, m, lv, pt)
