@@ -21,6 +21,9 @@ CASES = [  # N, Cin, Cout, D, H, W, stride, bias
     (2, 24, 24, 3, 4, 64, 1, False), (1, 8, 32, 2, 3, 128, 1, False), (1, 32, 16, 3, 2, 64, 1, False),   # LDS-transposed wgrad
     (1, 48, 48, 3, 3, 64, 1, False), (1, 40, 64, 2, 2, 64, 1, True),    # ... in 32-channel blocks
     (2, 1, 32, 3, 4, 32, 1, False), (1, 1, 8, 2, 3, 48, 1, False), (3, 1, 24, 5, 3, 16, 1, False),   # Cin=1: MFMA weight gradient
+    # >= 2^16 voxels, stride 1, <= 24 -> <= 32 channels: the LDS halo-tile kernel, partial tiles on every axis
+    (1, 24, 24, 18, 22, 200, 1, False), (1, 8, 32, 20, 30, 120, 1, True), (2, 16, 24, 17, 33, 136, 1, False),
+    (1, 1, 24, 18, 30, 128, 1, False),
 ]
 
 

@@ -207,6 +207,163 @@ __global__ __launch_bounds__(256) void conv3d_k3_igemm(const unsigned short* __r
 }
 
 // ---------------------------------------------------------------------------
+// implicit GEMM with the input halo tile in LDS (stride 1, Cin = 8 * CPT <= 24, Cout <= 32: the full-resolution
+// layers -- stem, 24 -> 24 forward and its data gradient).  conv3d_k3_igemm fetches every activation fragment
+// from global memory once per tap (27 x, 5 buffer loads per 4 MFMAs: bound by the vector-memory pipe at
+// ~20 % of the matrix cores); here a workgroup owns 4 x 4 x 32 output voxels at a time, stages their 6 x 6 x 34 halo
+// once (2.4 x the tile instead of 27 x) and the fragments are 16-byte LDS reads.  With the voxel pitch of
+// 16 / 48 bytes the 16 lanes of a quarter wave start in 16 distinct 4-bank groups: conflict-free.
+// Wave w owns the four 32-voxel rows of depth w; D is computed transposed as above.
+// ---------------------------------------------------------------------------
+template <int I> struct ConvIntC { static constexpr int value = I; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_conv(F&& f) {
+  if constexpr (I < N) {
+    f(ConvIntC<I>{});
+    static_for_conv<I + 1, N>(f);
+  }
+}
+
+constexpr int kLtD = 4, kLtH = 4, kLtW = 32;
+constexpr int kLtHaloVox = (kLtD + 2) * (kLtH + 2) * (kLtW + 2);
+
+template <int CPT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ wk,
+                                                        const float* __restrict__ bias,
+                                                        unsigned short* __restrict__ y, ConvGeom g, int tiles_d,
+                                                        int tiles_h, int tiles_w, long n_tiles, unsigned x_bytes,
+                                                        unsigned w_bytes) {
+  constexpr int VP = CPT * 16;                    // bytes per voxel (Cin = 8 * CPT channels)
+  constexpr int MT = kLtH;
+  __shared__ __attribute__((aligned(16))) unsigned char halo[kLtHaloVox * VP];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+
+  // A workgroup walks the tiles_w tiles of one (n, td, th) row; rows in contiguous ranges per XCD (workgroups are
+  // dealt round-robin to the 8 XCDs): neighbouring rows share halo voxels through the same L2.  The halo of the
+  // next tile is fetched into registers while this one is multiplied.
+  const long per = (n_tiles + 7) >> 3;            // n_tiles: rows here
+  const long trow = static_cast<long>(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (trow >= n_tiles || (blockIdx.x >> 3) >= per) return;
+  const int th = static_cast<int>(trow % tiles_h);
+  const long t2 = trow / tiles_h;
+  const int td = static_cast<int>(t2 % tiles_d);
+  const int n = static_cast<int>(t2 / tiles_d);
+  const int d0 = td * kLtD, h0 = th * kLtH;
+
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x), 0, static_cast<int>(x_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wk), 0, static_cast<int>(w_bytes), 0x00020000);
+
+  // ---- halo -> registers -> LDS, 16-byte pieces; outside the volume: zeros (buffer bounds check)
+  constexpr int PIECES = kLtHaloVox * CPT;
+  constexpr int ROUNDS = (PIECES + 255) / 256;
+  u32x4c stage[ROUNDS];
+  auto fetch = [&](int w0) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int p = r * 256 + static_cast<int>(threadIdx.x);
+      const int hv = p / CPT, c = p - hv * CPT;
+      const int row = hv / (kLtW + 2), wi = hv - row * (kLtW + 2);
+      const int hd = row / (kLtH + 2), hh = row - hd * (kLtH + 2);
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + wi;
+      const bool ok = p < PIECES && static_cast<unsigned>(d) < static_cast<unsigned>(g.D) &&
+                      static_cast<unsigned>(h) < static_cast<unsigned>(g.H) && static_cast<unsigned>(w) < static_cast<unsigned>(g.W);
+      const unsigned off = ok ? (static_cast<unsigned>(((n * g.D + d) * g.H + h) * g.W + w) * CPT + c) * 16u : kOOB;
+      stage[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+    }
+  };
+  fetch(0);
+  for (int tw = 0; tw < tiles_w; ++tw) {
+  const int w0 = tw * kLtW;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int p = r * 256 + static_cast<int>(threadIdx.x);
+    if (p < PIECES) *reinterpret_cast<u32x4c*>(halo + p * 16) = stage[r];
+  }
+  __syncthreads();
+  if (tw + 1 < tiles_w) fetch(w0 + kLtW);
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // K = (kd | kh, kw, c8): a run-time loop over the three kd planes, the 9 * CPT chunks of a plane as
+  // ceil(9 CPT / 2) fully unrolled K-steps (half-wave h takes chunk 2 * step + h; an odd last chunk multiplies by
+  // zero weights).  Inside a plane (tap, c8) are compile-time constants per half: the LDS offset of a fragment is a
+  // select between two immediates.  The weight fragment (global, L1) is fetched one step ahead.
+  constexpr int n_chunks = 9 * CPT;
+  constexpr int n_steps = (n_chunks + 1) / 2;
+  const unsigned char* lane_base = halo + ((wave * (kLtH + 2)) * (kLtW + 2) + col) * VP;
+  const unsigned w_lane = static_cast<unsigned>(col) * g.CinP * 2u;
+  const bool co_ok = col < g.Cout;
+  const unsigned w_tap = static_cast<unsigned>(g.Cout) * g.CinP * 2u;       // bytes per tap
+#pragma unroll 1
+  for (int kd = 0; kd < 3; ++kd) {
+    const unsigned char* plane = lane_base + kd * (kLtH + 2) * (kLtW + 2) * VP;
+    const unsigned w_plane = kd * 9 * w_tap + w_lane;
+    auto weight_fragment = [&](auto sc) {
+      constexpr int step = decltype(sc)::value;
+      constexpr int q0 = 2 * step, q1 = 2 * step + 1;
+      constexpr int tap0 = q0 / CPT, c80 = q0 % CPT, tap1 = (q1 < n_chunks ? q1 : q0) / CPT, c81 = (q1 < n_chunks ? q1 : q0) % CPT;
+      const int tap = half ? tap1 : tap0, c8 = half ? c81 : c80;
+      const bool chunk_ok = half ? (q1 < n_chunks) : true;
+      const unsigned woff = (co_ok && chunk_ok) ? w_plane + tap * w_tap + c8 * 16 : kOOB;
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, woff, 0, 0));
+    };
+    bf16x8 wf_cur = weight_fragment(ConvIntC<0>{});
+    static_for_conv<0, n_steps>([&](auto sc) {
+      constexpr int step = decltype(sc)::value;
+      constexpr int q0 = 2 * step, q1 = 2 * step + 1;
+      constexpr int tap0 = q0 / CPT, c80 = q0 % CPT, tap1 = (q1 < n_chunks ? q1 : q0) / CPT, c81 = (q1 < n_chunks ? q1 : q0) % CPT;
+      constexpr int off0 = ((tap0 / 3) * (kLtW + 2) + tap0 % 3) * VP + c80 * 16;
+      constexpr int off1 = ((tap1 / 3) * (kLtW + 2) + tap1 % 3) * VP + c81 * 16;
+      bf16x8 wf_next = wf_cur;
+      if constexpr (step + 1 < n_steps) wf_next = weight_fragment(ConvIntC<step + 1>{});
+      // activation fragments: B[k][j = voxel] = halo[(wave + kd, t + kh, col + kw)][c8*8 .. +8]
+      const unsigned char* src = plane + (half ? off1 : off0);
+      bf16x8 xf[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4c*>(src + t * (kLtW + 2) * VP));
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_cur, xf[t], acc[t], 0, 0, 0);
+      wf_cur = wf_next;
+    });
+  }
+
+  // epilogue: D[i = cout][j = voxel]; lane: col j, rows (r&3) + 8*(r>>2) + 4*half
+  const int od = d0 + wave, ow = w0 + col;
+  if (od < g.D && ow < g.W) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int oh = h0 + t;
+      if (oh >= g.H) continue;
+      unsigned short* yrow = y + (static_cast<long>((n * g.D + od) * g.H + oh) * g.W + ow) * g.Cout;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int co = 8 * gq + 4 * half;
+        if (co < g.Cout) {      // Cout % 4 == 0 (checked on the host)
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
+          u32x2c pk;
+          pk[0] = static_cast<unsigned>(f2bf(o[0])) | (static_cast<unsigned>(f2bf(o[1])) << 16);
+          pk[1] = static_cast<unsigned>(f2bf(o[2])) | (static_cast<unsigned>(f2bf(o[3])) << 16);
+          *reinterpret_cast<u32x2c*>(yrow + co) = pk;
+        }
+      }
+    }
+  }
+  __syncthreads();          // every wave is done with this halo before the next one lands
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient, K = voxels.
 //   gyT  (Cout, V)       bf16, V = N*Do*Ho*Wo, voxel-contiguous (channels first)
 //   xT3  (3, Cin, N, D, H, W) bf16: xT3[kw][ci][n][d][h][w] = x[n][d][h][w+kw-1][ci]
@@ -524,6 +681,20 @@ extern "C" int transoar_conv3d_k3_forward(const void* x, const void* wk, const f
   auto xp = static_cast<const unsigned short*>(x);
   auto wp = static_cast<const unsigned short*>(wk);
   auto yp = static_cast<unsigned short*>(y);
+  // full-resolution stride-1 layers with few channels: halo tile in LDS (conv3d_k3_lds)
+  static const bool no_lds = getenv("TRANSOAR_CONV_NO_LDS") != nullptr;
+  if (!no_lds && !dilated_input && stride == 1 && Cout <= 32 && (Cin == 8 || Cin == 16 || Cin == 24) &&
+      static_cast<long>(D) * H * W >= (1L << 16)) {
+    const int tiles_d = (D + kLtD - 1) / kLtD, tiles_h = (H + kLtH - 1) / kLtH, tiles_w = (W + kLtW - 1) / kLtW;
+    const long n_tiles = static_cast<long>(N) * tiles_d * tiles_h;      // rows of tiles_w tiles: one workgroup each
+    const dim3 lgrid(static_cast<unsigned>(((n_tiles + 7) / 8) * 8));
+#define TRANSOAR_CONV_LDS(CPTV)                                                                              \
+  hipLaunchKernelGGL((conv3d_k3_lds<CPTV>), lgrid, dim3(256), 0, st, xp, wp, bias, yp, g, tiles_d, tiles_h, tiles_w, \
+                     n_tiles, static_cast<unsigned>(x_bytes), static_cast<unsigned>(w_bytes))
+    if (Cin == 8) TRANSOAR_CONV_LDS(1); else if (Cin == 16) TRANSOAR_CONV_LDS(2); else TRANSOAR_CONV_LDS(3);
+#undef TRANSOAR_CONV_LDS
+    return static_cast<int>(hipGetLastError());
+  }
   // register blocking per wave: 4 voxel tiles x 1 cout tile (Cout <= 32) or 2 x 2 (64 accumulator
   // registers either way, 3 waves per SIMD to cover the load latency)
   const bool wide = Cout > 32;
