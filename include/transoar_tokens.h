@@ -18,6 +18,10 @@
  *   level_start (L) int32 first token of each level, S = tokens per batch element
  *   keep     (rows, cols) mask bytes of the branch's dropout (r is the branch BEFORE dropout:
  *            the kernels apply keep ? r * keep_scale : 0), or NULL when r is already final
+ *   keep_seed, keep_prob: the dropout mask without mask bytes (keep == NULL): element pair p = e / 2 of the
+ *            tensor is kept where 16-bit halves of hash32(p * 0x9e3779b9 + *keep_seed) are below
+ *            keep_prob * 65536 (hash32: the two-multiply xorshift finaliser in csrc/tokens.hip); *keep_seed is
+ *            one int32 on the device, drawn per call by the host from its generator.  NULL = no such mask.
  *   mean_rstd (rows, 2) fp32 written by forward, read by backward
  * cols must be a multiple of 128 and <= 1024.  Device pointers, 16-byte
  * aligned, asynchronous on `hip_stream`.  Returns 0, a hipError_t (> 0) or a
@@ -43,7 +47,7 @@ int transoar_add_layernorm_forward(const void* x, int x_is_bf16, const void* r, 
                                    const float* level_embed, const int* level_start, int L, long S,
                                    float* y32, void* y16, void* q16, float* mean_rstd, long rows,
                                    int cols, const unsigned char* keep, float keep_scale,
-                                   void* hip_stream);
+                                   const int* keep_seed, float keep_prob, void* hip_stream);
 
 /*
  * Backward.  g32 / g16 / gq16 are the gradients w.r.t. y32 / y16 / q16 (any of
@@ -58,7 +62,8 @@ int transoar_add_layernorm_backward(const float* g32, const void* g16, const voi
                                     int x_is_bf16, const void* r, const float* weight,
                                     const float* mean_rstd, const int* level_start, int L, long S,
                                     void* gx, void* gr16, float* partials, long rows, int cols,
-                                    const unsigned char* keep, float keep_scale, void* hip_stream);
+                                    const unsigned char* keep, float keep_scale, const int* keep_seed,
+                                    float keep_prob, void* hip_stream);
 
 /*
  * FFN activation of the layer, one pass each way (decoder_blocks.py:171-172,
@@ -66,8 +71,8 @@ int transoar_add_layernorm_backward(const float* g32, const void* g16, const voi
  *   y  = keep ? relu(h) * keep_scale : 0        keep: n mask bytes, NULL = keep all
  *   gh = y > 0 ? gy * keep_scale : 0            (y > 0  <=>  kept and h > 0)
  */
-int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale, void* y,
-                                  long n, void* hip_stream);
+int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale,
+                                  const int* keep_seed, float keep_prob, void* y, long n, void* hip_stream);
 int transoar_relu_dropout_backward(const void* gy, const void* y, float keep_scale, void* gh, long n,
                                    void* hip_stream);
 int transoar_add_layernorm_partial_rows(void);

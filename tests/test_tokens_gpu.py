@@ -154,3 +154,35 @@ def test_sampling_head_matches_eager_chain(geom, shared_ref):
     assert float((attn - w).abs().max()) <= 1e-6
     err = float((g_proj.float() - g_ref.float()).abs().max())
     assert err <= 2.0 ** -7 * float(g_ref.float().abs().max()), err
+
+
+def test_seeded_dropout_matches_hashed_mask():
+    """Dropout from a per-call seed (no mask tensor): the kernels' mask equals tokens.hashed_keep() of the same
+    seed, forward and backward, and keeps the requested fraction."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import tokens
+    torch.manual_seed(3)
+    dev, cols, rows, p = "cuda", 384, 1200, 0.1
+    scale = 1.0 / (1.0 - p)
+    seed = tokens.dropout_seed(torch.zeros(1, device=dev))
+    assert seed.dtype == torch.int32 and seed.numel() == 1
+    keep = tokens.hashed_keep(seed, rows * cols, 1.0 - p).view(1, rows, cols)
+    assert 0.89 < keep.float().mean().item() < 0.91
+    assert not torch.equal(keep, tokens.hashed_keep(tokens.dropout_seed(seed), rows * cols, 1.0 - p).view(1, rows, cols))
+    norm = torch.nn.LayerNorm(cols).to(dev)
+    x0 = torch.randn(1, rows, cols, device=dev)
+    r0 = torch.randn(1, rows, cols, device=dev).to(torch.bfloat16)
+    g = torch.randn(1, rows, cols, device=dev)
+    res = []
+    for k in (seed, keep):
+        x = x0.clone().requires_grad_(True); r = r0.clone().requires_grad_(True)
+        norm.zero_grad()
+        y32, y16, _ = tokens._AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, None, None, None, k, scale)
+        (y32 * g).sum().backward()
+        res.append((y32, y16, x.grad, r.grad, norm.weight.grad.clone()))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    h0 = torch.randn(rows, 1024, device=dev).to(torch.bfloat16)
+    keep2 = tokens.hashed_keep(seed, h0.numel(), 1.0 - p).view_as(h0)
+    assert torch.equal(tokens._ReluDropout.apply(h0, seed, scale), tokens._ReluDropout.apply(h0, keep2, scale))

@@ -33,10 +33,29 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Where a dropout keep-mask comes from: bytes in memory (1 = keep), or a counter-based hash of the element index
+// and a per-call seed drawn from torch's generator (nothing is written or read: 240 MB per FFN hidden tensor
+// less, each way).  Two elements per call: low byte / bit 8 of the result, like two mask bytes.
+struct KeepSrc {
+  const unsigned short* bytes;
+  const int* seed;
+  unsigned thr16;        // keep when a uniform 16-bit value < thr16
+  __device__ __forceinline__ bool active() const { return bytes != nullptr || seed != nullptr; }
+};
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned short keep_pair(const KeepSrc& ks, unsigned seed, long pair) {
+  if (ks.bytes != nullptr) return ks.bytes[pair];
+  const unsigned h = hash32(static_cast<unsigned>(pair) * 0x9e3779b9u + seed);
+  return static_cast<unsigned short>(((h & 0xffffu) < ks.thr16 ? 1u : 0u) | ((h >> 16) < ks.thr16 ? 0x100u : 0u));
+}
+
 // row of the residual stream (+ branch) into registers
 // (the branch r may still need its dropout: keep[e] != 0 -> r[e] * scale, else 0)
 template <int K, bool XBF>
-__device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, const unsigned short* keep, float scale,
+__device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, const KeepSrc& keep, float scale,
                                          long row, int cols, int lane, float (&v)[2 * K],
                                          unsigned short (&mask)[K]) {
 #pragma unroll
@@ -54,8 +73,8 @@ __device__ __forceinline__ void load_sum(const void* x, const unsigned int* r, c
       const unsigned int u = r[e >> 1];
       float ra = bf16_lo(u), rb = bf16_hi(u);
       mask[i] = 0x0101;
-      if (keep != nullptr) {
-        const unsigned short m = keep[e >> 1];          // two mask bytes
+      if (keep.active()) {
+        const unsigned short m = keep_pair(keep, keep.seed ? static_cast<unsigned>(*keep.seed) : 0u, e >> 1);   // two mask bytes
         mask[i] = m;
         ra = (m & 0xffu) ? ra * scale : 0.f;
         rb = (m >> 8) ? rb * scale : 0.f;
@@ -78,7 +97,7 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_fwd(
     const float* __restrict__ bias, float eps, const float* __restrict__ pos_sine,
     const float* __restrict__ level_embed, const int* __restrict__ level_start, int L, long S,
     float* __restrict__ y32, unsigned int* __restrict__ y16, unsigned int* __restrict__ q16,
-    float* __restrict__ mean_rstd, long rows, const unsigned short* __restrict__ keep, float scale) {
+    float* __restrict__ mean_rstd, long rows, KeepSrc keep, float scale) {
   constexpr int cols = 128 * K;
   const int lane = threadIdx.x & 63;
   const long row = static_cast<long>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
     const void* __restrict__ x, const unsigned int* __restrict__ r, const float* __restrict__ weight,
     const float* __restrict__ mean_rstd, const int* __restrict__ level_start, int L, long S,
     void* __restrict__ gx, unsigned int* __restrict__ gr16, float* __restrict__ partials, long rows,
-    const unsigned short* __restrict__ keep, float scale) {
+    KeepSrc keep, float scale) {
   constexpr int cols = 128 * K;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
       }
       if (gr16 != nullptr) {                      // gradient of the (pre-dropout) branch
         float r0 = d0, r1 = d1;
-        if (keep != nullptr) {
+        if (keep.active()) {
           r0 = (mask[i] & 0xffu) ? d0 * scale : 0.f;
           r1 = (mask[i] >> 8) ? d1 * scale : 0.f;
         }
@@ -210,17 +229,17 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
 }
 
 // y = keep ? relu(h) * scale : 0 on bf16, 8 elements per thread
-__global__ __launch_bounds__(256) void relu_dropout_fwd(const uint4* __restrict__ h, const uint2* __restrict__ keep,
-                                                        float scale, uint4* __restrict__ y, long n8) {
+__global__ __launch_bounds__(256) void relu_dropout_fwd(const uint4* __restrict__ h, KeepSrc keep, float scale,
+                                                        uint4* __restrict__ y, long n8) {
   const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n8) return;
   const uint4 u = h[i];
-  const uint2 m = keep != nullptr ? keep[i] : uint2{0x01010101u, 0x01010101u};
+  const unsigned seed = keep.seed ? static_cast<unsigned>(*keep.seed) : 0u;
   const unsigned int in[4] = {u.x, u.y, u.z, u.w};
   unsigned int out[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const unsigned int mb = (j < 2 ? m.x : m.y) >> (16 * (j & 1));
+    const unsigned int mb = keep.active() ? keep_pair(keep, seed, 4 * i + j) : 0x0101u;
     const float a = fmaxf(bf16_lo(in[j]), 0.f), b = fmaxf(bf16_hi(in[j]), 0.f);
     out[j] = pack_bf16((mb & 0xffu) ? a * scale : 0.f, (mb & 0xff00u) ? b * scale : 0.f);
   }
@@ -318,6 +337,11 @@ __global__ __launch_bounds__(256) void sampling_head_bwd(const float* __restrict
 
 }  // namespace
 
+static unsigned keep_threshold(float keep_prob) {
+  const float t = keep_prob * 65536.0f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : static_cast<unsigned>(t));
+}
+
 #define TOK_DISPATCH(K_, BODY) \
   switch (K_) {                \
     case 1: { constexpr int K = 1; BODY; break; } \
@@ -334,7 +358,7 @@ extern "C" int transoar_add_layernorm_forward(const void* x, int x_is_bf16, cons
                                               const float* level_embed, const int* level_start, int L, long S,
                                               float* y32, void* y16, void* q16, float* mean_rstd, long rows,
                                               int cols, const unsigned char* keep, float keep_scale,
-                                              void* hip_stream) {
+                                              const int* keep_seed, float keep_prob, void* hip_stream) {
   if (!x || !weight || !bias || !y32 || !y16 || !mean_rstd) return TRANSOAR_TOK_ERR_NULL;
   if (q16 && (!pos_sine || !level_embed || !level_start)) return TRANSOAR_TOK_ERR_NULL;
   if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
@@ -344,7 +368,7 @@ extern "C" int transoar_add_layernorm_forward(const void* x, int x_is_bf16, cons
   auto rr = static_cast<const unsigned int*>(r);
   auto o16 = static_cast<unsigned int*>(y16);
   auto oq = static_cast<unsigned int*>(q16);
-  auto kp = reinterpret_cast<const unsigned short*>(keep);
+  const KeepSrc kp{reinterpret_cast<const unsigned short*>(keep), keep_seed, keep_threshold(keep_prob)};
   TOK_DISPATCH(cols / 128, {
     if (x_is_bf16)
       hipLaunchKernelGGL((add_ln_fwd<K, true>), grid, block, 0, st, x, rr, weight, bias, eps, pos_sine, level_embed,
@@ -360,7 +384,8 @@ extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16
                                                int x_is_bf16, const void* r, const float* weight,
                                                const float* mean_rstd, const int* level_start, int L, long S,
                                                void* gx, void* gr16, float* partials, long rows, int cols,
-                                               const unsigned char* keep, float keep_scale, void* hip_stream) {
+                                               const unsigned char* keep, float keep_scale, const int* keep_seed,
+                                               float keep_prob, void* hip_stream) {
   if (!x || !weight || !mean_rstd || !gx || !partials) return TRANSOAR_TOK_ERR_NULL;
   if (gq16 && !level_start) return TRANSOAR_TOK_ERR_NULL;
   if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
@@ -371,7 +396,7 @@ extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16
   auto aq = static_cast<const unsigned int*>(gq16);
   auto rr = static_cast<const unsigned int*>(r);
   auto o16 = static_cast<unsigned int*>(gr16);
-  auto kp = reinterpret_cast<const unsigned short*>(keep);
+  const KeepSrc kp{reinterpret_cast<const unsigned short*>(keep), keep_seed, keep_threshold(keep_prob)};
   TOK_DISPATCH(cols / 128, {
     if (x_is_bf16)
       hipLaunchKernelGGL((add_ln_bwd<K, true>), grid, block, 0, st, g32, a16, aq, x, rr, weight, mean_rstd,
@@ -383,14 +408,16 @@ extern "C" int transoar_add_layernorm_backward(const float* g32, const void* g16
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale, void* y,
+extern "C" int transoar_relu_dropout_forward(const void* h, const unsigned char* keep, float keep_scale,
+                                             const int* keep_seed, float keep_prob, void* y,
                                              long n, void* hip_stream) {
   if (!h || !y) return TRANSOAR_TOK_ERR_NULL;
   if (n <= 0 || (n & 7)) return TRANSOAR_TOK_ERR_DIM;
   const long n8 = n >> 3;
   hipLaunchKernelGGL(relu_dropout_fwd, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(h),
-                     reinterpret_cast<const uint2*>(keep), keep_scale, static_cast<uint4*>(y), n8);
+                     KeepSrc{reinterpret_cast<const unsigned short*>(keep), keep_seed, keep_threshold(keep_prob)}, keep_scale,
+                     static_cast<uint4*>(y), n8);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -432,4 +459,4 @@ extern "C" int transoar_sampling_head_backward(const float* g_loc, const float* 
 }
 
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 3; }
+extern "C" int transoar_tokens_abi_version(void) { return 4; }

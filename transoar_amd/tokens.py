@@ -24,11 +24,11 @@ def _load():
     lib = ctypes.CDLL(_LIB_PATH)
     i, p, lg, f = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
     lib.transoar_add_layernorm_forward.restype = i
-    lib.transoar_add_layernorm_forward.argtypes = [p, i, p, p, p, f, p, p, p, i, lg, p, p, p, p, lg, i, p, f, p]
+    lib.transoar_add_layernorm_forward.argtypes = [p, i, p, p, p, f, p, p, p, i, lg, p, p, p, p, lg, i, p, f, p, f, p]
     lib.transoar_add_layernorm_backward.restype = i
-    lib.transoar_add_layernorm_backward.argtypes = [p, p, p, p, i, p, p, p, p, i, lg, p, p, p, lg, i, p, f, p]
+    lib.transoar_add_layernorm_backward.argtypes = [p, p, p, p, i, p, p, p, p, i, lg, p, p, p, lg, i, p, f, p, f, p]
     lib.transoar_relu_dropout_forward.restype = i
-    lib.transoar_relu_dropout_forward.argtypes = [p, p, f, p, lg, p]
+    lib.transoar_relu_dropout_forward.argtypes = [p, p, f, p, f, p, lg, p]
     lib.transoar_relu_dropout_backward.restype = i
     lib.transoar_relu_dropout_backward.argtypes = [p, p, f, p, lg, p]
     lib.transoar_add_layernorm_partial_rows.restype = i
@@ -37,7 +37,7 @@ def _load():
     lib.transoar_sampling_head_backward.restype = i
     lib.transoar_sampling_head_backward.argtypes = [p, p, p, p, p, lg, i, i, i, p]
     lib.transoar_tokens_abi_version.restype = i
-    if lib.transoar_tokens_abi_version() != 3:
+    if lib.transoar_tokens_abi_version() != 4:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -54,6 +54,15 @@ def usable(x, r, cols):
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def _keep_args(keep, scale):
+    """(mask bytes, scale, seed, keep probability) of the C ABI from `keep`: None, a uint8 mask or an int32 seed."""
+    if keep is None:
+        return None, float(scale), None, 1.0
+    if keep.dtype == torch.int32:
+        return None, float(scale), keep.data_ptr(), 1.0 / float(scale)
+    return keep.data_ptr(), float(scale), None, 1.0
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -76,7 +85,7 @@ class _AddLayerNorm(torch.autograd.Function):
             rc = lib.transoar_add_layernorm_forward(
                 x.data_ptr(), int(x.dtype == torch.bfloat16), _ptr(r), w32.data_ptr(), b32.data_ptr(), float(eps),
                 _ptr(pos_sine), _ptr(le32), _ptr(level_start), n_lvl, s_tokens, y32.data_ptr(), y16.data_ptr(),
-                _ptr(q16), stats.data_ptr(), rows, cols, _ptr(keep), float(keep_scale),
+                _ptr(q16), stats.data_ptr(), rows, cols, *_keep_args(keep, keep_scale),
                 torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_add_layernorm_forward failed with code %d" % rc)
@@ -106,7 +115,8 @@ class _AddLayerNorm(torch.autograd.Function):
             rc = lib.transoar_add_layernorm_backward(
                 _ptr(g32), _ptr(g16), _ptr(gq16), x.data_ptr(), int(x_bf16), _ptr(r), w32.data_ptr(),
                 stats.data_ptr(), _ptr(level_start), n_lvl, ctx.s_tokens, gx.data_ptr(), _ptr(gr),
-                partials.data_ptr(), rows, cols, _ptr(keep), ctx.keep_scale, torch.cuda.current_stream().cuda_stream)
+                partials.data_ptr(), rows, cols, *_keep_args(keep, ctx.keep_scale),
+                torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_add_layernorm_backward failed with code %d" % rc)
         sums = partials.sum(0)
@@ -126,15 +136,41 @@ def dropout_mask(like, p):
     return torch.empty(like.shape, dtype=torch.uint8, device=like.device).bernoulli_(1.0 - p)
 
 
+SEEDED_DROPOUT = os.environ.get("TRANSOAR_DROPOUT_BYTES", "0") != "1"
+
+
+def dropout_seed(like):
+    """One int32 from torch's generator (capture-safe) on like's device: the kernels derive the keep-mask of the
+    call from it by hashing the element index -- no mask tensor is written or read."""
+    return torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int32, device=like.device)
+
+
+def hashed_keep(seed, numel, keep_prob):
+    """The mask the kernels derive from `seed` (int32 tensor of 1 element), as numel uint8 -- test reference of
+    keep_pair() in csrc/tokens.hip."""
+    m32 = 0xffffffff
+    pair = torch.arange((numel + 1) // 2, dtype=torch.int64, device=seed.device)
+    x = (pair * 0x9e3779b9 + (seed.to(torch.int64) & m32)) & m32
+    x = x ^ (x >> 16)
+    x = (x * 0x7feb352d) & m32
+    x = x ^ (x >> 15)
+    x = (x * 0x846ca68b) & m32
+    x = x ^ (x >> 16)
+    thr = min(max(int(keep_prob * 65536.0 + 0.5), 0), 65535)
+    keep = torch.stack(((x & 0xffff) < thr, (x >> 16) < thr), dim=1).reshape(-1)[:numel]
+    return keep.to(torch.uint8)
+
+
 def add_layernorm(x, r, norm, pos_sine=None, level_embed=None, level_start=None, dropout=None):
     """-> (y32, y16, q16 or None).  x (..., C) fp32/bf16 residual stream, r bf16 branch or None,
     norm an nn.LayerNorm over C.  With pos_sine (S, C) fp32 (no grad), level_embed (L, C) and
     level_start (L,) int32, q16 = bf16(y + (pos_sine[s] + level_embed[level(s)])).
     dropout: the nn.Dropout that the reference applies to the branch first (applied inside the
-    kernel from a byte mask when it is active)."""
+    kernel when it is active: from a per-call seed, or a byte mask with TRANSOAR_DROPOUT_BYTES=1)."""
     keep, scale = None, 1.0
     if dropout is not None and dropout.training and dropout.p > 0.0 and r is not None:
-        keep, scale = dropout_mask(r, dropout.p), 1.0 / (1.0 - dropout.p)
+        keep = dropout_seed(r) if SEEDED_DROPOUT else dropout_mask(r, dropout.p)
+        scale = 1.0 / (1.0 - dropout.p)
     return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, pos_sine, level_embed, level_start, keep, scale)
 
 
@@ -143,7 +179,7 @@ class _ReluDropout(torch.autograd.Function):
     def forward(ctx, h, keep, scale):
         y = torch.empty_like(h)
         with torch.cuda.device(h.device):
-            rc = lib.transoar_relu_dropout_forward(h.data_ptr(), _ptr(keep), float(scale), y.data_ptr(), h.numel(),
+            rc = lib.transoar_relu_dropout_forward(h.data_ptr(), *_keep_args(keep, scale), y.data_ptr(), h.numel(),
                                                    torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_relu_dropout_forward failed with code %d" % rc)
@@ -167,7 +203,7 @@ class _ReluDropout(torch.autograd.Function):
 def relu_dropout(h, dropout):
     """dropout(relu(h)) for a contiguous bf16 CUDA tensor (numel % 8 == 0) in one pass each way."""
     active = dropout.training and dropout.p > 0.0
-    keep = dropout_mask(h, dropout.p) if active else None
+    keep = (dropout_seed(h) if SEEDED_DROPOUT else dropout_mask(h, dropout.p)) if active else None
     return _ReluDropout.apply(h, keep, 1.0 / (1.0 - dropout.p) if active else 1.0)
 
 
