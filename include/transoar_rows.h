@@ -20,6 +20,12 @@ int transoar_rows_gather(const void* src, const int* index, void* out, int B, lo
 int transoar_rows_pull_sum(const void* g, const int* inv_ptr, const int* inv_idx, void* out, int B,
                            long S, long K, int row_bytes, int is_bf16, void* hip_stream);
 
+/* out[c] = sum_r x[r][c]: x (rows, cols) bf16, fp32 accumulation, out (cols) fp32; cols % 8 == 0, cols <= 2048.
+ * workspace: transoar_rows_colsum_workspace_floats(cols) floats.  Replaces the bias-gradient reductions
+ * grad.sum(0) of nn.Linear / nn.Conv3d(bias=True) under autocast. */
+int transoar_rows_colsum(const void* x, float* out, float* workspace, long rows, int cols, void* hip_stream);
+int transoar_rows_colsum_workspace_floats(int cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,3 +25,20 @@ def test_rows_gather_and_pull_sum(dtype):
     ref = torch.zeros(B, S, C, device="cuda").index_add_(1, index.cuda(), gy.float())
     tol = 1e-6 if dtype == torch.float32 else 2 ** -7
     assert float((got.float() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(234000, 384), (50000, 1024), (4096, 8), (70001, 24), (9999, 2048)])
+def test_colsum_matches_fp32_sum(shape):
+    """Column sums of a bf16 matrix (bias gradients): fp32 accumulation, against torch's fp32 sum of the same values
+    (different summation order: 1e-5 relative to the column's absolute sum)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import rows
+    torch.manual_seed(shape[1])
+    x = torch.randn(shape, device="cuda").to(torch.bfloat16)
+    assert rows.colsum_usable(x)
+    got = rows.colsum(x)
+    ref = x.double().sum(0)
+    bound = 1e-5 * x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (shape[1],)
+    assert bool(((got.double() - ref).abs() <= bound + 1e-6).all())

@@ -24,8 +24,21 @@ def test_matches_autocast_linear(tokens, n_in, n_out, in_dtype):
         res.append((y, xi.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
     (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = res
     assert y1.dtype == torch.bfloat16 and gx1.dtype == in_dtype and gw1.dtype == torch.float32
-    assert torch.equal(y0, y1)
-    assert torch.equal(gx0, gx1)
+    from transoar_amd import token_linear as tl
+    if tl.LAST_PATH == "blas":
+        assert torch.equal(y0, y1)
+        assert torch.equal(gx0, gx1)
+    else:
+        # hand-written GEMM (K = N = 384): the bias is added in fp32 before the single rounding to bf16 and the
+        # K loop runs in another order -> a result may differ from hipBLASLt's by one bf16 ulp; both are
+        # measured against fp64 of the same bf16 operands
+        xb, wb = x[0].to(torch.bfloat16).double(), lin.weight.detach().to(torch.bfloat16).double()
+        ty = xb @ wb.t() + lin.bias.detach().double()
+        e0, e1 = (y0[0].double() - ty).abs().max(), (y1[0].double() - ty).abs().max()
+        assert e1 <= max(e0, 2.0 ** -8 * ty.abs().max())
+        tgx = gy[0].double() @ wb
+        g0, g1 = (gx0[0].double() - tgx).abs().max(), (gx1[0].double() - tgx).abs().max()
+        assert g1 <= max(g0, 2.0 ** -8 * tgx.abs().max())
     # fp64 truth for the weight gradient: both paths must be equally close to it
     truth = gy[0].double().t() @ x[0].to(torch.bfloat16).double()
     scale = truth.abs().max()

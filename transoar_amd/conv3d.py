@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _native  # noqa: F401  (torch's HIP runtime first)
+from . import rows as _rows
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
@@ -272,7 +273,8 @@ class _Conv3dK3(torch.autograd.Function):
             if need_w and not hip_w:
                 gw = aw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gyb.float().sum(dim=(0, 2, 3, 4))
+            g2 = gyb.permute(0, 2, 3, 4, 1).reshape(-1, gyb.shape[1])        # channels-last: a view, rows = voxels
+            gb = _rows.colsum(g2) if _rows.colsum_usable(g2) else gyb.float().sum(dim=(0, 2, 3, 4))
         return gx, gw, gb, None
 
 

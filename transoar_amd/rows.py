@@ -15,6 +15,28 @@ lib.transoar_rows_gather.restype = _i
 lib.transoar_rows_gather.argtypes = [_p, _p, _p, _i, _l, _l, _i, _p]
 lib.transoar_rows_pull_sum.restype = _i
 lib.transoar_rows_pull_sum.argtypes = [_p, _p, _p, _p, _i, _l, _l, _i, _i, _p]
+lib.transoar_rows_colsum.restype = _i
+lib.transoar_rows_colsum.argtypes = [_p, _p, _p, _l, _i, _p]
+lib.transoar_rows_colsum_workspace_floats.restype = _i
+lib.transoar_rows_colsum_workspace_floats.argtypes = [_i]
+
+
+def colsum_usable(x):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.is_contiguous()
+            and x.shape[1] % 8 == 0 and x.shape[1] <= 2048 and x.shape[0] >= 4096)
+
+
+def colsum(x):
+    """x (rows, cols) bf16 contiguous -> (cols,) fp32 column sums (fp32 accumulation)."""
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    work = torch.empty(lib.transoar_rows_colsum_workspace_floats(cols), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_rows_colsum(x.data_ptr(), out.data_ptr(), work.data_ptr(), rows, cols,
+                                      torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise RuntimeError("transoar_rows_colsum failed with code %d" % rc)
+    return out
 
 
 def usable(x):

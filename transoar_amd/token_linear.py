@@ -23,7 +23,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import gemm
+from . import gemm, rows
 
 MIN_TOKENS = 32768          # below this the stock path is as fast
 LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
@@ -92,7 +92,7 @@ class _TokenLinear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = gy2.sum(0, dtype=torch.float32)
+                gb = rows.colsum(gy2) if rows.colsum_usable(gy2) else gy2.sum(0, dtype=torch.float32)
         return gx, gw, gb
 
 
