@@ -11,3 +11,6 @@ rm -f gpurun_out/r02_prof_bench/p_kernel_trace.csv
 bash tools/collect_msda_pmc.sh gpurun_out/r02_msda_pmc > /dev/null 2>&1
 python tools/bench_msda.py --iters 20 --dtypes bf16 > gpurun_out/r02_msda_op_bench.jsonl 2>/dev/null; cat gpurun_out/r02_msda_op_bench.jsonl | cut -c1-200
 python tools/bench_gemm.py > gpurun_out/r02_gemm_bench.jsonl 2>/dev/null
+python tools/bench_conv.py > gpurun_out/r02_conv_layers.jsonl 2>/dev/null; cut -c1-160 gpurun_out/r02_conv_layers.jsonl | head -4
+TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --no-graph --steps 20 --warmup 5 > gpurun_out/r02_bench_one_rank_rccl.json 2>/dev/null; python tools/_pr.py gpurun_out/r02_bench_one_rank_rccl.json
+TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --graph --steps 20 --warmup 5 > gpurun_out/r02_bench_one_rank_rccl_graph.json 2>/dev/null; python tools/_pr.py gpurun_out/r02_bench_one_rank_rccl_graph.json

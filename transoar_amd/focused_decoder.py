@@ -115,17 +115,8 @@ class FocusedAttn(nn.Module):
         else:
             self.pos_bias = None
 
-    def _roi_attention(self, q, v, k_pos, roi):
-        """Per-organ attention over the organ's own keys; keys = v + k_pos.
-        roi = (index (O,L) long, pad (O,L) bool True=padding); queries are
-        organ-major."""
-        index, pad, inverse = roi[0], roi[1], roi[2:]
-        b, n_q, c = q.shape
-        n_org, n_keys = index.shape
-        qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
-        # gather the organ's tokens BEFORE the projections: one scatter in the backward
-        # (d_src = Wk^T dk + Wv^T dv) instead of one per projection
-        flat = index.reshape(-1)
+    def _roi_tokens(self, v, k_pos, flat, inverse):
+        """-> (gathered value tokens (B, O*L, C), key tokens = value tokens + gathered positions)"""
         v_tok = _GatherTokens.apply(v.contiguous(), flat, inverse)         # (B, O*L, C)
         if k_pos is None:
             k_tok = v_tok
@@ -147,6 +138,29 @@ class FocusedAttn(nn.Module):
             k_tok = v_tok + hit[1]
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())
+        return v_tok, k_tok
+
+    def _roi_attention(self, q, v, k_pos, roi, roi_cache=None):
+        """Per-organ attention over the organ's own keys; keys = v + k_pos.
+        roi = (index (O,L) long, pad (O,L) bool True=padding); queries are
+        organ-major.  roi_cache: a dict shared by the layers of ONE decoder forward whose key lists are equal:
+        the gathered value / key tokens depend only on (v, k_pos), so the first layer's are reused."""
+        index, pad, inverse = roi[0], roi[1], roi[2:]
+        b, n_q, c = q.shape
+        n_org, n_keys = index.shape
+        qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
+        # gather the organ's tokens BEFORE the projections: one scatter in the backward
+        # (d_src = Wk^T dk + Wv^T dv) instead of one per projection
+        flat = index.reshape(-1)
+        hit_tok = None
+        if roi_cache is not None and roi_cache.get("v") is v and roi_cache.get("k_pos") is k_pos:
+            hit_tok = roi_cache["tok"]
+        if hit_tok is not None:
+            v_tok, k_tok = hit_tok
+        else:
+            v_tok, k_tok = self._roi_tokens(v, k_pos, flat, inverse)
+            if roi_cache is not None:
+                roi_cache.update(v=v, k_pos=k_pos, tok=(v_tok, k_tok))
         # (GPU only: on the CPU the 8x larger contraction of the folded form is slower than two projections)
         if FocusedAttn.fold_projections and q.is_cuda and self.pos_bias is None \
                 and not (self.training and self.attn_drop.p > 0):
@@ -193,12 +207,12 @@ class FocusedAttn(nn.Module):
             out = out + self.v_proj.bias.view(h, hd).to(out.dtype)
         return out.reshape(b, n_q, c)
 
-    def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None):
+    def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None, roi_cache=None):
         """q (B,Nq,C), k/v (B,Nkv,C); mask additive (Nq,Nkv) of 0/-inf; roi: the
         same mask as per-organ key lists.  k_pos: if given, the keys are
         ``v + k_pos`` and ``k`` may be None.  Returns (out, weights or None)."""
         if roi is not None and not need_weights and (k_pos is not None or k is v):
-            return self.proj_drop(self.proj(self._roi_attention(q, v, k_pos, roi))), None
+            return self.proj_drop(self.proj(self._roi_attention(q, v, k_pos, roi, roi_cache))), None
         if k is None:
             k = v + k_pos
         b, n_kv, c = k.shape
@@ -320,7 +334,7 @@ class FocusedDecoderLayer(nn.Module):
             pad[o, : ids.numel()] = False
         return index, pad
 
-    def forward(self, tgt, query_pos, src_pos, src, need_weights=False):
+    def forward(self, tgt, query_pos, src_pos, src, need_weights=False, roi_cache=None):
         q = k = tgt if query_pos is None else tgt + query_pos
         sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                             need_weights=False)[0].transpose(0, 1)
@@ -329,7 +343,7 @@ class FocusedDecoderLayer(nn.Module):
         q = tgt if query_pos is None else tgt + query_pos
         roi = (self.roi_index, self.roi_pad, self.roi_inv_ptr, self.roi_inv_idx) if self._use_roi else None
         ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self._dense_bias,
-                                      need_weights=need_weights, roi=roi, k_pos=src_pos)
+                                      need_weights=need_weights, roi=roi, k_pos=src_pos, roi_cache=roi_cache)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
         ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
@@ -342,16 +356,21 @@ class FocusedDecoderModel(nn.Module):
         self.layers = nn.ModuleList(copy.deepcopy(decoder_layer) for _ in range(num_layers))
         self.num_layers = num_layers
         self.return_intermediate = return_intermediate
+        # deep copies of one layer: equal per-organ key lists -> the gathered key / value tokens are shared
+        first = self.layers[0]
+        self._shared_roi = bool(getattr(first, "_use_roi", False)) and all(
+            getattr(l, "_use_roi", False) and torch.equal(l.roi_index, first.roi_index) for l in self.layers)
 
     def forward(self, tgt, src, src_pos, query_pos=None):
         out, stack = tgt, []
+        roi_cache = {} if self._shared_roi else None
         if src.is_cuda and src.dtype == torch.float32 and torch.is_autocast_enabled() \
                 and torch.get_autocast_gpu_dtype() == torch.bfloat16:
             # every consumer of src in the layers is a bf16 GEMM operand under autocast: round it once
             # for all layers instead of gathering / adding fp32 tokens and casting them per layer
             src = src.to(torch.bfloat16)
         for layer in self.layers:
-            out, _ = layer(out, query_pos, src_pos, src)
+            out, _ = layer(out, query_pos, src_pos, src, roi_cache=roi_cache)
             if self.return_intermediate:
                 stack.append(out)
         return torch.stack(stack) if self.return_intermediate else out
