@@ -105,3 +105,24 @@ def test_use_cuda_false_needs_an_injected_core():
               torch.tensor([[2, 2, 2]]), torch.tensor([0]))
     finally:
         mod.register_debug_core(prev)
+
+
+def test_sampling_head_and_colsum_argument_errors():
+    tok = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_tokens.so"))
+    rows = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_rows.so"))
+    buf = (ctypes.c_char * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    p, lg, i = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    f = tok.transoar_sampling_head_forward
+    f.argtypes = [p, p, lg, p, p, p, lg, i, i, i, p]
+    assert f(None, p16, 4, p16, p16, p16, 4, 6, 4, 4, None) == -1
+    assert f(p16, p16, 4, p16, p16, p16, 4, 6, 65, 4, None) == -2           # L * P > 256
+    assert f(p16, p16, 3, p16, p16, p16, 4, 6, 4, 4, None) == -2            # tokens not a multiple of ref_rows
+    b = tok.transoar_sampling_head_backward
+    b.argtypes = [p, p, p, p, p, lg, i, i, i, p]
+    assert b(p16, p16, None, p16, p16, 4, 6, 4, 4, None) == -1
+    c = rows.transoar_rows_colsum
+    c.argtypes = [p, p, p, lg, i, p]
+    assert c(None, p16, p16, 8, 8, None) == -1
+    assert c(p16, p16, p16, 8, 12, None) == -2                             # cols not a multiple of 8
+    assert rows.transoar_rows_colsum_workspace_floats(384) == 1024 * 384
