@@ -141,10 +141,9 @@ class Decoder(nn.Module):
                 use_cuda=config["use_cuda"])
 
     def forward(self, x):
-        # the encoder hands over channels-last (NDHWC) bf16 maps on the GPU; everything from here
-        # on is a torch/MIOpen convolution whose tuned kernels are keyed on NCDHW (miopen_db/)
-        # (Conv3dK3.ndhwc_everywhere: keep channels-last all the way -- MIOpen's CK solvers are NDHWC natively;
-        # needs find-db entries for the NDHWC keys of every layer of this decoder)
+        # the encoder hands over channels-last (NDHWC) bf16 maps on the GPU; everything from here on is a
+        # torch/MIOpen convolution.  Conv3dK3.ndhwc_everywhere (default): keep channels-last all the way -- MIOpen's
+        # CK solvers are NDHWC natively and miopen_db/ has entries for these keys; otherwise convert to NCDHW first
         feats = list(x.values())[-self._lateral_levels:]
         if not Conv3dK3.ndhwc_everywhere:
             feats = [to_ncdhw(f) for f in feats]
