@@ -556,6 +556,20 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
   u32x4 pre[8];
   bool have_pre = false;
   int cell_start = 0;
+  // The results of a lane (per level: 2 points x (3 + 1) gradients, 2 ranks) stay in registers until the end of the
+  // wave: written level by level, the four 8..24-byte pieces of a query's 64 / 192-byte rows arrive microseconds
+  // apart with 20 MB of such rows in flight on the chip, and L2 evicted the half-written lines (WRITE_SIZE 2.3 x
+  // the payload).
+  float res_a[kMmaLevels][2], res_l[kMmaLevels][2][3];
+  int res_rank[kMmaLevels][2];
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      res_a[l][pi] = 0.f; res_rank[l][pi] = -1;
+      res_l[l][pi][0] = 0.f; res_l[l][pi][1] = 0.f; res_l[l][pi][2] = 0.f;
+    }
+  });
   static_for<0, kMmaLevels>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     if (l >= L) return;
@@ -563,19 +577,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const int level_cells = (D + 1) * (H + 1) * (W + 1);
     const int my_cell_start = cell_start;
     cell_start += level_cells;
-    const long jx = item * LP + l * P + 2 * kg;
-    if (box[l].TD == 0) {                        // no valid point of the wave: zero gradients, no ranks
-      if (live) {
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-          if (bin_count != nullptr) bin_rank[jx + pi] = -1;
-          Elem<LT>::st(grad_attn + jx + pi, 0.f);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) Elem<LT>::st(grad_loc + 3 * (jx + pi) + k, 0.f);
-        }
-      }
-      return;
-    }
+    if (box[l].TD == 0) return;                  // no valid point of the wave: zero gradients, no ranks
     const MmaBox bx = box[l];
     const int THW = bx.TH * bx.TW, R = bx.TD * THW;
 
@@ -617,10 +619,8 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
           if (rank[pi] >= 0) rank[pi] += hist[lcell[pi]];
         // the histogram lived in the G block: its spare row was not touched, the rest is rewritten before use
       }
-      if (live) {
-        bin_rank[jx] = rank[0];
-        bin_rank[jx + 1] = rank[1];
-      }
+      res_rank[l][0] = rank[0];
+      res_rank[l][1] = rank[1];
     }
 
     // ---- this lane's 16 corner slots: word offset in a G block that would hold the whole box
@@ -757,13 +757,36 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
           py += (dh ? dot : -dot) * (wd * ww);
           pz += (dd ? dot : -dot) * (wh * ww);
         }
-        Elem<LT>::st(grad_attn + jx + pi, pa);
-        Elem<LT>::st(grad_loc + 3 * (jx + pi), px * g.a * static_cast<float>(W));
-        Elem<LT>::st(grad_loc + 3 * (jx + pi) + 1, py * g.a * static_cast<float>(H));
-        Elem<LT>::st(grad_loc + 3 * (jx + pi) + 2, pz * g.a * static_cast<float>(D));
+        res_a[l][pi] = pa;
+        res_l[l][pi][0] = px * g.a * static_cast<float>(W);
+        res_l[l][pi][1] = py * g.a * static_cast<float>(H);
+        res_l[l][pi][2] = pz * g.a * static_cast<float>(D);
       }
     }
   });
+
+  if (live) {
+    static_for<0, kMmaLevels>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      if (l >= L) return;
+      const long jx = item * LP + l * P + 2 * kg;          // even: 8-byte aligned pairs
+      if (bin_count != nullptr) *reinterpret_cast<int2*>(bin_rank + jx) = int2{res_rank[l][0], res_rank[l][1]};
+      if constexpr (sizeof(LT) == 4) {
+        *reinterpret_cast<float2*>(grad_attn + jx) = float2{res_a[l][0], res_a[l][1]};
+        float2* gl = reinterpret_cast<float2*>(grad_loc + 3 * jx);
+        gl[0] = float2{res_l[l][0][0], res_l[l][0][1]};
+        gl[1] = float2{res_l[l][0][2], res_l[l][1][0]};
+        gl[2] = float2{res_l[l][1][1], res_l[l][1][2]};
+      } else {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          Elem<LT>::st(grad_attn + jx + pi, res_a[l][pi]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Elem<LT>::st(grad_loc + 3 * (jx + pi) + k, res_l[l][pi][k]);
+        }
+      }
+    });
+  }
 }
 
 }  // namespace transoar
