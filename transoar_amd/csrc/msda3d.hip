@@ -399,10 +399,17 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
     // brick-owner schedule: fp32 LDS tile per 4x4x8 brick, 8-weight point records
     if (r_order.enabled && fold_count && d.C == kTileC && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
       auto recs8 = reinterpret_cast<PointW8<float>*>(ws + w.recs);
+      auto recs4 = reinterpret_cast<PointT4*>(ws + w.recs);        // matrix-core walks: 32 bytes with the row index inside
+      bool mma = false;
+      if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
       {
         ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
-        hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
-                           rank, recs8, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
+        if (mma)
+          hipLaunchKernelGGL((msda3d_cell_fill_t4<LT>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count, rank, recs4,
+                             d.M, d.L, d.Lq, d.P, w.n_points);
+        else
+          hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
+                             rank, recs8, rec_item, d.M, d.L, d.Lq, d.P, w.n_points);
       }
       // levels whose voxels receive >= kCoarsePointsPerVoxel points each go to the chunked walk
       CoarseLevels cl{d.L, static_cast<int>(cells_per_slab), d.S, 0, 0};
@@ -436,12 +443,10 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         ProfScope prof(TRANSOAR_PROF_VALUE_CELLS, cst);
         TRANSOAR_CHECK_HIP(zero_async(scratch, sizeof(float) * scratch_elems, cst));
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
-        bool mma = false;
-        if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
         if (mma) {
           if constexpr (sizeof(VT) == 2)       // 16 sorted points per MFMA K-step (msda3d_cells_mma.hpp)
             hipLaunchKernelGGL((msda3d_bwd_value_cells_mma<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0,
-                               cst, go, count, recs8, rec_item, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
+                               cst, go, count, recs4, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
                                cl_d, r_order_d);
         } else {
           hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
@@ -453,12 +458,10 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       ProfScope prof(TRANSOAR_PROF_VALUE_TILE, st);
       if (fine_bricks > 0) {
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
-        bool mma = false;
-        if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
         if (mma) {
           if constexpr (sizeof(VT) == 2)
             hipLaunchKernelGGL((msda3d_bwd_value_tile_mma<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st,
-                               go, count, recs8, rec_item, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
+                               go, count, recs4, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
                                d.S, d.M, fine_bricks, n_wg, r_order_d);
         } else {
           hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
