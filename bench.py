@@ -78,7 +78,7 @@ def pmc_traffic(kind, dims):
         if not same:
             return None
         if kind == "bwd":       # the whole chain
-            names = [k for k in pmc["kernels"] if k.startswith("bwd_") or k in ("cell_fill_w8", "scan_tiles", "coarse_rows_store")]
+            names = [k for k in pmc["kernels"] if k.startswith("bwd_") or k.startswith("cell_fill") or k in ("scan_tiles", "coarse_rows_store")]
             return round(sum(pmc["kernels"][k].get("hbm_bytes_per_launch", 0.0) for k in names) / 1e6, 1)
         return round(pmc["kernels"]["fwd_mma"]["hbm_bytes_per_launch"] / 1e6, 1)
     except Exception:
