@@ -105,12 +105,21 @@ __global__ __launch_bounds__(256) void colsum_partial(const u32x4r* __restrict__
   }
 }
 
+// 32 columns per workgroup, 8 row lanes of 128 partials each, the 8 sums meet in LDS
 __global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ partials, float* __restrict__ out, int cols) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float sh[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float a = 0.f;
-  for (int b = 0; b < kColsumBlocks; ++b) a += partials[static_cast<long>(b) * cols + c];
-  out[c] = a;
+  if (c < cols)
+    for (int b = grp; b < kColsumBlocks; b += 8) a += partials[static_cast<long>(b) * cols + c];
+  sh[grp][cl] = a;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+#pragma unroll
+    for (int g = 1; g < 8; ++g) a += sh[g][cl];
+    out[c] = a;
+  }
 }
 
 }  // namespace transoar
@@ -154,6 +163,6 @@ extern "C" int transoar_rows_colsum(const void* x, float* out, float* workspace,
   const int vpr = cols / 8, rpb = 256 / vpr;
   hipLaunchKernelGGL(colsum_partial, dim3(kColsumBlocks), dim3(256), 0, st, static_cast<const u32x4r*>(x), workspace, rows,
                      vpr, rpb);
-  hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, out, cols);
+  hipLaunchKernelGGL(colsum_final, dim3((cols + 31) / 32), dim3(256), 0, st, workspace, out, cols);
   return static_cast<int>(hipGetLastError());
 }

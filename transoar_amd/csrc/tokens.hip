@@ -287,13 +287,17 @@ __global__ __launch_bounds__(256) void sampling_head_fwd(const unsigned short* _
   const float logit = __uint_as_float(static_cast<unsigned>(row[3 * M * G + m * G + g]) << 16);
   sh[threadIdx.x] = logit;
   __syncthreads();
-  const float* grp = sh + (threadIdx.x - g);
+  float* grp = sh + (threadIdx.x - g);
   float mx = grp[0];
   for (int i = 1; i < G; ++i) mx = fmaxf(mx, grp[i]);
+  const float ex = __expf(logit - mx);           // one exponential per thread; the group's sum through LDS again
+  __syncthreads();
+  sh[threadIdx.x] = ex;
+  __syncthreads();
   float sum = 0.f;
-  for (int i = 0; i < G; ++i) sum += __expf(grp[i] - mx);
+  for (int i = 0; i < G; ++i) sum += grp[i];
   if (!live) return;
-  attn[e] = __expf(logit - mx) / sum;
+  attn[e] = ex / sum;
   const int l = g / P;
   const unsigned short* o = row + (m * G + g) * 3;
 #pragma unroll
