@@ -62,6 +62,12 @@ int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N,
                              int W, int Cin, int Do, int Ho, int Wo, int Cout, int stride_dh,
                              void* hip_stream);
 
+/* The Cin = 1 stem on the matrix cores without a channel-padded copy of the volume: x (N, D, H, W) bf16,
+ * wk (27, Cout, 8) bf16 with the real input channel first, y (N, D, H, W, Cout) bf16; stride 1, Cout % 4 == 0, <= 32
+ * (encoder_blocks.py:28-35 with in_channels = 1). */
+int transoar_conv3d_k3_forward_c1(const void* x, const void* wk, const float* bias, void* y, int N, int D, int H,
+                                  int W, int Cout, void* hip_stream);
+
 /*
  * First layer, Cin == 1, stride 1: stencil.
  *   x (N, D, H, W) bf16 ; w (27, Cout) fp32 ; y (N, D, H, W, Cout) bf16 ; Cout % 8 == 0, Cout <= 64

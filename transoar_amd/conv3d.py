@@ -37,6 +37,8 @@ def _load():
     lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 10 + [p]
     lib.transoar_conv3d_c1_wgrad.restype = i
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
+    lib.transoar_conv3d_k3_forward_c1.restype = i
+    lib.transoar_conv3d_k3_forward_c1.argtypes = [p, p, p, p] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
     lib.transoar_conv3d_c1_forward.argtypes = [p, p, p] + [i] * 5 + [p]
     lib.transoar_layout_bf16.restype = i
@@ -135,6 +137,17 @@ def conv3d_k3_forward(x, wk, bias, stride, dilated_input=False):
     return y
 
 
+def conv3d_k3_forward_c1(x, wk, bias):
+    """x (N, 1, D, H, W) bf16 contiguous, wk (27, Cout, 8) -> (N, Cout, D, H, W) bf16 channels-last, stride 1"""
+    n, _, d, h, w = x.shape
+    cout = wk.shape[1]
+    y = torch.empty((n, d, h, w, cout), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_k3_forward_c1(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 y.data_ptr(), n, d, h, w, cout, _stream()), "conv3d_k3_forward_c1")
+    return y.permute(0, 4, 1, 2, 3)
+
+
 def wgrad_operands(x, gy, stride):
     """Channels-first operands of the weight-gradient GEMM (K = voxels):
     gyT (Cout,N,Do,Ho,Wo) and xT3 (3,Cin,N,D,H,Wo), the three W-shifted (and for
@@ -217,11 +230,15 @@ class _Conv3dK3(torch.autograd.Function):
             # (K = 27 taps x 8); the scalar stencil kernel (transoar_conv3d_c1_forward) is VALU-bound at a
             # seventh of this speed -- 1.6 ms vs 0.35 ms on the 2x160x160x256 volume
             n, _, d, h, w = xb.shape
-            x8 = torch.zeros((n, d, h, w, 8), dtype=torch.bfloat16, device=x.device)
-            x8[..., 0] = xb.view(n, d, h, w)
             w8 = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, 7))
-            y = conv3d_k3_forward(x8.permute(0, 4, 1, 2, 3), _pack_taps(w8),
-                                  bias.float() if bias is not None else None, stride)
+            b32 = bias.float() if bias is not None else None
+            if stride == 1 and weight.shape[0] <= 32 and d * h * w >= (1 << 16):
+                # the LDS halo-tile kernel reads the one-channel volume itself (zero-extends while staging)
+                y = conv3d_k3_forward_c1(xb, _pack_taps(w8), b32)
+            else:
+                x8 = torch.zeros((n, d, h, w, 8), dtype=torch.bfloat16, device=x.device)
+                x8[..., 0] = xb.view(n, d, h, w)
+                y = conv3d_k3_forward(x8.permute(0, 4, 1, 2, 3), _pack_taps(w8), b32, stride)
         else:
             y = conv3d_k3_forward(xb, _pack_taps(weight), bias.float() if bias is not None else None, stride)
         ctx.save_for_backward(xb, weight)

@@ -227,7 +227,7 @@ __device__ __forceinline__ void static_for_conv(F&& f) {
 constexpr int kLtD = 4, kLtH = 4, kLtW = 32;
 constexpr int kLtHaloVox = (kLtD + 2) * (kLtH + 2) * (kLtW + 2);
 
-template <int CPT>
+template <int CPT, bool C1 = false>      // C1: the input has ONE channel (2 bytes per voxel), zero-extended to 8 while staging
 __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ wk,
                                                         const float* __restrict__ bias,
@@ -272,8 +272,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
       const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + wi;
       const bool ok = p < PIECES && static_cast<unsigned>(d) < static_cast<unsigned>(g.D) &&
                       static_cast<unsigned>(h) < static_cast<unsigned>(g.H) && static_cast<unsigned>(w) < static_cast<unsigned>(g.W);
-      const unsigned off = ok ? (static_cast<unsigned>(((n * g.D + d) * g.H + h) * g.W + w) * CPT + c) * 16u : kOOB;
-      stage[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      if constexpr (C1) {
+        const unsigned off = ok ? static_cast<unsigned>(((n * g.D + d) * g.H + h) * g.W + w) * 2u : kOOB;
+        const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(xr, off, 0, 0);
+        stage[r] = u32x4c{static_cast<unsigned>(v), 0u, 0u, 0u};
+      } else {
+        const unsigned off = ok ? (static_cast<unsigned>(((n * g.D + d) * g.H + h) * g.W + w) * CPT + c) * 16u : kOOB;
+        stage[r] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      }
     }
   };
   fetch(0);
@@ -707,6 +713,29 @@ extern "C" int transoar_conv3d_k3_forward(const void* x, const void* wk, const f
   if (dilated_input) { if (wide) TRANSOAR_CONV(2, 2, true); else TRANSOAR_CONV(4, 1, true); }
   else { if (wide) TRANSOAR_CONV(2, 2, false); else TRANSOAR_CONV(4, 1, false); }
 #undef TRANSOAR_CONV
+  return static_cast<int>(hipGetLastError());
+}
+
+// Cin = 1 stem through the LDS kernel without materialising a channel-padded copy of the volume:
+// x (N, D, H, W) bf16, wk (27, Cout, 8) with the one real input channel first (the other 7 are multiplied by the
+// zeros the staging writes).  Stride 1, Cout <= 32.
+extern "C" int transoar_conv3d_k3_forward_c1(const void* x, const void* wk, const float* bias, void* y, int N, int D,
+                                             int H, int W, int Cout, void* hip_stream) {
+  if (!x || !wk || !y) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if ((Cout & 3) || Cout > 32) return TRANSOAR_CONV_ERR_CHANNELS;
+  ConvGeom g;
+  g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = 8; g.Cout = Cout; g.CinP = 8; g.stride = 1;
+  g.Do = D; g.Ho = H; g.Wo = W;
+  const long x_bytes = static_cast<long>(N) * D * H * W * 2;
+  const long w_bytes = 27L * Cout * 8 * 2;
+  if (!fits32(x_bytes) || static_cast<long>(N) * D * H * W >= (1L << 31)) return TRANSOAR_CONV_ERR_DIM;
+  const int tiles_d = (D + kLtD - 1) / kLtD, tiles_h = (H + kLtH - 1) / kLtH, tiles_w = (W + kLtW - 1) / kLtW;
+  const long n_rows = static_cast<long>(N) * tiles_d * tiles_h;
+  hipLaunchKernelGGL((conv3d_k3_lds<1, true>), dim3(static_cast<unsigned>(((n_rows + 7) / 8) * 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(x),
+                     static_cast<const unsigned short*>(wk), bias, static_cast<unsigned short*>(y), g, tiles_d, tiles_h,
+                     tiles_w, n_rows, static_cast<unsigned>(x_bytes), static_cast<unsigned>(w_bytes));
   return static_cast<int>(hipGetLastError());
 }
 
