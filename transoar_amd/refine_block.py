@@ -50,10 +50,10 @@ def map_to_tokens(fmap):
 
 
 def tokens_to_map(tokens, shape):
-    """(N, V, C) -> (N, C, D, H, W); a channels_last_3d VIEW when the tokens are
-    contiguous (no copy), which later flattens back to tokens for free."""
+    """(N, V, C) -> (N, C, D, H, W); a channels-last VIEW when the token rows are dense (no copy), which later
+    flattens back to tokens for free."""
     n, _, c = tokens.shape
-    if tokens.is_contiguous():
+    if tokens.stride(2) == 1 and tokens.stride(1) == c:     # contiguous, or one level cut out of the (N, S, C) pyramid
         return tokens.view(n, *shape, c).permute(0, 4, 1, 2, 3)
     return tokens.transpose(1, 2).reshape(n, c, *shape)
 
@@ -180,7 +180,8 @@ class DecoderDefAttnBlock(nn.Module):
             pos = torch.cat([self._pos_tokens(p, lvl) + self.level_embed[lvl].view(1, 1, -1).to(p.dtype)
                              for lvl, p in enumerate(pos_embeds)], dim=1)
             memory = self.refine_def_attn(tokens, spatial, starts, pos, ref)
-        return [tokens_to_map(m.contiguous(), shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
+        # views into the token matrix (batch stride = the whole pyramid): no copies, the levels nobody reads cost nothing
+        return [tokens_to_map(m, shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
 
     def _fused_ok(self, tokens, pos_embeds):
         return (tokens.is_cuda and tokens.dtype == torch.bfloat16 and tokens.is_contiguous()
