@@ -54,3 +54,40 @@ def test_small_inputs_take_the_stock_path():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = token_linear(x, lin.weight, lin.bias)
     assert "TokenLinear" not in type(y.grad_fn).__name__
+
+
+def test_fpn_pointwise_convs_as_token_gemms():
+    """The FPN decoder's 1x1x1 lateral and k = s = 2 transposed convolutions on the hand-written GEMM
+    (backbone._conv1_as_gemm / _up2_as_gemm) against the stock convolutions: outputs and gradients within bf16
+    rounding of each other."""
+    import copy
+    from tests import _inputs
+    from transoar_amd import backbone
+    torch.manual_seed(0)
+    cfg = _inputs.small_backbone_config(False, levels=("P2", "P3", "P4", "P5"))
+    cfg.update(start_channels=8, out_fmaps=["P2", "P3", "P4", "P5"])
+    dec = backbone.Decoder(cfg).cuda()
+    shapes = [(8, 32, 32, 64), (16, 16, 16, 32), (32, 8, 8, 16), (64, 4, 4, 8), (128, 2, 2, 4), (256, 1, 1, 2)]
+    feats0 = {"C%d" % i: torch.randn(2, *s, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+              for i, s in enumerate(shapes)}
+    res = []
+    for flag in (True, False):
+        backbone.Decoder.gemm_pointwise = flag
+        d = copy.deepcopy(dec)
+        feats = {k: v.clone().requires_grad_() for k, v in feats0.items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = d(feats)
+        loss = sum((o.float() * torch.linspace(-1, 1, o.numel(), device="cuda").view_as(o)).sum() for o in out.values())
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
+        res.append((out, grads, {k: v.grad for k, v in feats.items() if v.grad is not None}))
+    backbone.Decoder.gemm_pointwise = True
+    (o1, g1, x1), (o0, g0, x0) = res
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-20)
+    assert set(o1) == set(o0) and set(g1) == set(g0) and set(x1) == set(x0) and len(x1) >= 4
+    for k in o0:
+        assert rel(o1[k], o0[k]) <= 2.0 ** -6, k
+    for k in g0:
+        assert rel(g1[k], g0[k]) <= 2.0 ** -5, k
+    for k in x0:
+        assert rel(x1[k], x0[k]) <= 2.0 ** -5, k

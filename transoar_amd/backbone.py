@@ -8,6 +8,8 @@ keys, same parameter names (``_encoder._stages.N._block.K``, ``_decoder._lateral
 The Swin encoder (``use_encoder_attn``) is outside this build's scope
  and raises.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -16,6 +18,7 @@ from .conv3d import Conv3dK3, to_ncdhw
 from .position_encoding import PositionEmbeddingLearned3D, PositionEmbeddingSine3D
 from .swin_encoder import ConvPatchMerging, EncoderSwinBlock, PatchMerging
 from .refine_block import DecoderDefAttnBlock
+from .token_linear import token_linear
 
 
 class EncoderCnnBlock(nn.Module):
@@ -89,7 +92,43 @@ class Encoder(nn.Module):
         return outputs
 
 
+def _gemm_conv_ok(f):
+    """channels-last bf16 map on the GPU under bf16 autocast: its voxels are the rows of a token matrix (a view)"""
+    return (f.is_cuda and f.dtype == torch.bfloat16 and f.dim() == 5 and f.shape[1] % 8 == 0
+            and f.is_contiguous(memory_format=torch.channels_last_3d)
+            and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+
+
+def _conv1_as_gemm(conv, f):
+    """Conv3d(kernel 1) of attn_fpn.py:55-63 as a token GEMM on csrc/gemm.hip: rows = voxels, (Cout, Cin) weights."""
+    n, c, d, h, w = f.shape
+    tok = f.permute(0, 2, 3, 4, 1).reshape(n, d * h * w, c)
+    y = token_linear(tok, conv.weight.view(conv.out_channels, c), conv.bias, force_hip=True, min_tokens=1024)
+    return y.view(n, d, h, w, conv.out_channels).permute(0, 4, 1, 2, 3)
+
+
+def _is_up2(up):
+    return (tuple(up.kernel_size) == (2, 2, 2) and tuple(up.stride) == (2, 2, 2) and tuple(up.padding) == (0, 0, 0)
+            and tuple(up.output_padding) == (0, 0, 0) and tuple(up.dilation) == (1, 1, 1) and up.groups == 1)
+
+
+def _up2_as_gemm(up, f):
+    """ConvTranspose3d(kernel = stride = 2) of attn_fpn.py:75-83: every input voxel writes its own 2x2x2 output block,
+    so it is one GEMM voxels x (8 Cout, Cin) followed by a pixel shuffle."""
+    n, c, d, h, w = f.shape
+    co = up.out_channels
+    tok = f.permute(0, 2, 3, 4, 1).reshape(n, d * h * w, c)
+    w8 = up.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, c)                   # rows ((kd, kh, kw), cout)
+    b8 = None if up.bias is None else up.bias.repeat(8)
+    y = token_linear(tok, w8, b8, force_hip=True, min_tokens=1024)              # (n, dhw, 8 co)
+    y = y.view(n, d, h, w, 2, 2, 2, co).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(n, 2 * d, 2 * h, 2 * w, co)
+    return y.permute(0, 4, 1, 2, 3)
+
+
 class Decoder(nn.Module):
+    # the FPN's 1x1x1 lateral and k = s = 2 transposed convolutions as token GEMMs on the hand-written kernel
+    gemm_pointwise = os.environ.get("TRANSOAR_FPN_STOCK_POINTWISE") is None
+
     def __init__(self, config, debug=False):
         super().__init__()
         self._debug = debug
@@ -147,7 +186,8 @@ class Decoder(nn.Module):
         feats = list(x.values())[-self._lateral_levels:]
         if not Conv3dK3.ndhwc_everywhere:
             feats = [to_ncdhw(f) for f in feats]
-        laterals = [conv(f) for conv, f in zip(self._lateral, feats)]
+        as_gemm = Decoder.gemm_pointwise and all(_gemm_conv_ok(f) for f in feats)
+        laterals = [(_conv1_as_gemm(conv, f) if as_gemm else conv(f)) for conv, f in zip(self._lateral, feats)]
         # merged[s - first] = lateral_s + up(merged_{s+1})
         merged = [None] * self._lateral_levels
         carry = None
@@ -155,7 +195,8 @@ class Decoder(nn.Module):
             cur = lat if carry is None else lat + carry
             merged[self._lateral_levels - 1 - k] = cur
             if k < self._lateral_levels - 1:
-                carry = self._up[k](cur)
+                up = self._up[k]
+                carry = _up2_as_gemm(up, cur) if (as_gemm and _is_up2(up)) else up(cur)
         outputs = {"P%d" % s: self._out[n](merged[s - self._first_stage])
                    for n, s in enumerate(self._required_stages)}
 

@@ -30,13 +30,13 @@ LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests
 USE_HIP_GEMM = {"1": True, "0": False}.get(os.environ.get("TRANSOAR_HIP_GEMM", ""), None)     # None: per shape
 
 
-def _hip_gemm(x2, w):
+def _hip_gemm(x2, w, force=False):
     """Hand-written kernel for this product?  (x2 (T, K), w (N, K))"""
     if not gemm.usable(x2, w):
         return False
     if USE_HIP_GEMM is not None:
         return USE_HIP_GEMM
-    return x2.shape[1] == 384 and w.shape[0] == 384
+    return force or (x2.shape[1] == 384 and w.shape[0] == 384)
 
 
 def _chunks(tokens, n_out, n_in):
@@ -61,14 +61,14 @@ def weight_grad(gy, x):
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, force_hip=False):
         xb = x.to(torch.bfloat16)
         wb = weight.to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
-        ctx.in_dtype, ctx.has_bias = x.dtype, bias is not None
+        ctx.in_dtype, ctx.has_bias, ctx.force_hip = x.dtype, bias is not None, force_hip
         global LAST_PATH
         x2 = xb.reshape(-1, xb.shape[-1])
-        if _hip_gemm(x2, wb):
+        if _hip_gemm(x2, wb, force_hip):
             LAST_PATH = "hip-gemm"
             # the bias is added in fp32 before the single rounding to bf16 (F.linear rounds the bias to bf16 first)
             return gemm.linear_nt(x2, wb, bias).view(*xb.shape[:-1], wb.shape[0])
@@ -87,21 +87,22 @@ class _TokenLinear(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
                 wt = wb.t().contiguous()                   # (K, N): dX = dY . W as an NT product
-                gx = gemm.linear_nt(gy2, wt) if _hip_gemm(gy2, wt) else torch.mm(gy2, wb)
+                gx = gemm.linear_nt(gy2, wt) if _hip_gemm(gy2, wt, ctx.force_hip) else torch.mm(gy2, wb)
                 gx = gx.view(xb.shape).to(ctx.in_dtype)
             if ctx.needs_input_grad[1]:
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = rows.colsum(gy2) if rows.colsum_usable(gy2) else gy2.sum(0, dtype=torch.float32)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def token_linear(x, weight, bias=None):
+def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
-    bf16 autocast on the GPU with enough tokens, the stock one otherwise."""
+    bf16 autocast on the GPU with enough tokens, the stock one otherwise.  force_hip: the hand-written GEMM for
+    the forward and the data gradient whatever the shape (the FPN's 1x1x1 and transposed convolutions)."""
     tokens = x.numel() // x.shape[-1]
-    if (x.is_cuda and tokens >= MIN_TOKENS
+    if (x.is_cuda and tokens >= (MIN_TOKENS if min_tokens is None else min_tokens)
             and weight.dtype == torch.float32 and x.is_contiguous()
             and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
-        return _TokenLinear.apply(x, weight, bias)
+        return _TokenLinear.apply(x, weight, bias, force_hip)
     return F.linear(x, weight, bias)
