@@ -422,7 +422,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       }
       cl.rows = d.S - cl.row_start;
       const int coarse_levels = d.L - cl.first;
-      cl.chunks_per_slab = static_cast<int>((static_cast<long>(d.Lq) * d.P * coarse_levels + kCellChunk - 1) / kCellChunk) + 1;
+      const int cell_chunk = mma ? kCmCellChunk : kCellChunk;
+      cl.chunks_per_slab = static_cast<int>((static_cast<long>(d.Lq) * d.P * coarse_levels + cell_chunk - 1) / cell_chunk) + 1;
       const int fine_bricks = r_order.pad_start[cl.first] >> 7;
       const BrickOrder* r_order_d = device_const(r_order);
       const CoarseLevels* cl_d = device_const(cl);

@@ -1,6 +1,6 @@
 // grad_value of the coarse levels on the matrix cores.
 //
-// Same unit of work as msda3d_bwd_value_cells (msda3d_tile.hpp): a wave owns kCellChunk consecutive SORTED
+// Same unit of work as msda3d_bwd_value_cells (msda3d_tile.hpp): a wave owns kCmCellChunk consecutive SORTED
 // points of the coarse levels of one (batch, head) slab and visits each exactly once.  The points of 7
 // consecutive cells along w (one (cd, ch) cell row) touch 2 x 2 x 8 = 32 voxels; their contribution
 //     dV[voxel, c] += sum_p  weight[voxel, p] * grad_out[item(p), c]
@@ -26,6 +26,7 @@
 namespace transoar {
 
 constexpr int kCellsWindow = 7;        // cells per window: 8 voxels along w
+constexpr int kCmCellChunk = 1024;     // sorted points per wave of the coarse walk (256: 2.41, 512: 2.35, 1024: 2.31, 2048: 2.44 ms per backward call)
 constexpr int kCmRowPitch = 144;       // bytes per staged grad_out row (128 + 16: spreads the banks, as kMmaVP)
 
 // Record of a sorted point for the matrix-core walks: ONE 32-byte write per point (the 8-weight record + a separate
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256, 4) void msda3d_bwd_value_cells_mma(
   const int slab = wid / cl.chunks_per_slab, chunk = wid - slab * cl.chunks_per_slab;
   if (slab >= n_slabs) return;
   const int* off = offset + static_cast<long>(slab) * cells_per_slab;
-  const int t0 = off[cl.cell_start] + chunk * kCellChunk;
-  const int end = min(t0 + kCellChunk, off[cells_per_slab]);
+  const int t0 = off[cl.cell_start] + chunk * kCmCellChunk;
+  const int end = min(t0 + kCmCellChunk, off[cells_per_slab]);
   if (t0 >= end) return;
   const int b = slab / M, m = slab - b * M;
   unsigned char* vrow = lds_rows[wave_in_wg];
