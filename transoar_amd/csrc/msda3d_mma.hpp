@@ -606,13 +606,24 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
       }
       if (use_hist) {
         const float inv_chw = __builtin_amdgcn_rcpf(static_cast<float>(CH * CW)), inv_cw = __builtin_amdgcn_rcpf(static_cast<float>(CW));
-        for (int c = lane; c < ncells; c += 64) {
-          const int n = hist[c];
-          if (n > 0) {
-            const int cd = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_chw), cr = c - cd * (CH * CW);
-            const int ch = static_cast<int>((static_cast<float>(cr) + 0.5f) * inv_cw), cw = cr - ch * CW;
-            hist[c] = atomicAdd(slab_count + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
+        // 8 cells per lane at a time with all their returning atomics in flight together (one after the other,
+        // each waiting for its result before the LDS write, this loop was 4 serial round trips per level)
+        for (int c0 = 0; c0 < ncells; c0 += 512) {
+          int base[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int c = c0 + 64 * k + lane;
+            const int n = c < ncells ? hist[c] : 0;
+            base[k] = -1;
+            if (n > 0) {
+              const int cd = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_chw), cr = c - cd * (CH * CW);
+              const int ch = static_cast<int>((static_cast<float>(cr) + 0.5f) * inv_cw), cw = cr - ch * CW;
+              base[k] = atomicAdd(slab_count + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
+            }
           }
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (base[k] >= 0) hist[c0 + 64 * k + lane] = base[k];
         }
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
