@@ -186,3 +186,27 @@ def test_seeded_dropout_matches_hashed_mask():
     h0 = torch.randn(rows, 1024, device=dev).to(torch.bfloat16)
     keep2 = tokens.hashed_keep(seed, h0.numel(), 1.0 - p).view_as(h0)
     assert torch.equal(tokens._ReluDropout.apply(h0, seed, scale), tokens._ReluDropout.apply(h0, keep2, scale))
+
+
+def test_dropout_seed_changes_on_every_graph_replay():
+    """The per-call dropout seed is drawn by torch's generator INSIDE the captured step: every replay must see a
+    new one (a seed frozen at capture time would repeat the same dropout mask every step)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import tokens
+    like = torch.zeros(1, device="cuda")
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out.copy_(tokens.dropout_seed(like))        # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out.copy_(tokens.dropout_seed(like))
+    seen = set()
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.add(int(out.item()))
+    assert len(seen) == 4, seen
