@@ -74,6 +74,7 @@ enum {
 #define TRANSOAR_MSDA3D_NO_BRICK 4u        /* per-item / voxel-stationary kernels even where the LDS-tiled ones apply */
 #define TRANSOAR_MSDA3D_FORK 8u             /* backward: run the coarse-level grad_value walk on an internal side stream */
 #define TRANSOAR_MSDA3D_NO_MMA 16u            /* forward: LDS-tiled per-corner kernel instead of the matrix-core gather */
+#define TRANSOAR_MSDA3D_MMA_Q32 32u           /* forward: round 2's matrix-core gather (32 queries per wave, fp32 weight block) instead of the point-column one */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*
@@ -101,6 +102,28 @@ int transoar_msda3d_forward(const void* value, const int64_t* spatial_shapes,
                             int Lq, int P, int value_dtype, int loc_dtype,
                             const int64_t* host_spatial_shapes, unsigned flags,
                             void* hip_stream);
+
+/*
+ * Forward with the module's sampling head fused into the gather (the fast path of
+ * MSDeformAttn.forward, ops/modules/ms_deform_attn.py:114-136: softmax over the
+ * L*P logits of a head, sampling_locations = reference_points + offsets / (W, H, D),
+ * then MSDeformAttnFunction).  Neither sampling_loc nor attn_weight is materialised:
+ *   proj  (N*S, 4*M*L*P) bf16  the stacked projection of the query tokens,
+ *         row = [sampling_offsets (M, L, P, 3) | attention logits (M, L*P)]
+ *   ref   (ref_rows, L, 3) fp32 reference points (x, y, z); ref_rows = S (shared
+ *         by the batch) or N*S
+ * The arithmetic is that of transoar_sampling_head_forward followed by
+ * transoar_msda3d_forward (the bf16 rounding points of the autocast chain).
+ * Queries must be the voxels of the pyramid (Lq == S), 16-bit value storage,
+ * C = 64, P = 4, L <= 4, host shapes required.  Returns TRANSOAR_ERR_DIM for
+ * other forms (use the two-call path).
+ */
+int transoar_msda3d_forward_fused(const void* value, const void* proj,
+                                  const float* ref, long ref_rows, void* out,
+                                  int N, int S, int M, int C, int L, int P,
+                                  int value_dtype,
+                                  const int64_t* host_spatial_shapes,
+                                  void* hip_stream);
 
 /*
  * Backward.  Writes grad_value (shape and dtype of value), grad_sampling_loc

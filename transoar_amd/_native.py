@@ -18,7 +18,7 @@ _LIB_NAME = "libtransoar_msda3d.so"
 
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FORCE_GENERIC = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NativeLibraryError(ImportError):
@@ -37,6 +37,9 @@ def _load():
     try:
         lib.transoar_msda3d_forward.restype = c_int
         lib.transoar_msda3d_forward.argtypes = [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_uint, c_void_p]
+        lib.transoar_msda3d_forward_fused.restype = c_int
+        lib.transoar_msda3d_forward_fused.argtypes = ([c_void_p] * 3 + [ctypes.c_long, c_void_p] + [c_int] * 7 +
+                                                      [c_void_p, c_void_p])
         lib.transoar_msda3d_backward.restype = c_int
         lib.transoar_msda3d_backward.argtypes = ([c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 9 +
                                                  [c_void_p, c_uint, c_void_p])

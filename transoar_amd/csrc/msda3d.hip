@@ -9,11 +9,13 @@
 // not: see the kernel headers.  Bound: HBM/L2 bandwidth (18 flop per gathered
 // byte); no MFMA in here.
 #include <algorithm>
+#include <cstring>
 
 #include "../../include/transoar_msda3d.h"
 #include "msda3d_common.hpp"
 #include "msda3d_brick.hpp"
 #include "msda3d_mma.hpp"
+#include "msda3d_pcm.hpp"
 #include "msda3d_tile.hpp"
 #include "msda3d_cells_mma.hpp"
 #include "msda3d_gather.hpp"
@@ -209,6 +211,37 @@ static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
   return w;
 }
 
+// Does the point-column gather (msda3d_pcm.hpp) cover this problem?  Queries = voxels of a <= 4-level pyramid
+// known on the host, 64 channels, 4 points, every buffer addressable with 32-bit byte offsets.
+static bool pcm_ok(const BrickOrder& order, const Dims& d) {
+  if (!order.enabled || d.L > kPcmLevels || d.C != 64 || d.P != 4 || d.Lq != d.S) return false;
+  for (int l = 0; l < d.L; ++l)
+    if (order.D[l] > 1000 || order.H[l] > 1000 || order.W[l] > 1000) return false;
+  const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
+  const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 16;
+  const long vbytes = static_cast<long>(d.N) * d.S * d.M * d.C * 2;
+  return n_pts * 12 < 0xfffffff0L && n_wave < (1L << 31) - 8 && vbytes < 0xffffff00L;
+}
+static float host_bf16_round(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&x, &u, 4);
+  return x;
+}
+static PcmConst make_pcm_const(const BrickOrder& order) {
+  PcmConst c;
+  memset(&c, 0, sizeof(c));
+  c.order = order;
+  for (int l = 0; l < 4; ++l) {
+    const int ls = l < order.L ? l : 0;
+    c.fD[l] = static_cast<float>(order.D[ls]); c.fH[l] = static_cast<float>(order.H[ls]); c.fW[l] = static_cast<float>(order.W[ls]);
+    c.dD[l] = host_bf16_round(c.fD[l]); c.dH[l] = host_bf16_round(c.fH[l]); c.dW[l] = host_bf16_round(c.fW[l]);
+  }
+  return c;
+}
+
 template <typename VT, typename LT>
 static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, void* out, const Dims& d,
@@ -230,6 +263,22 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
     // matrix-core gather: one wave per 32 queries (2x4x4 sub-brick) and head
     bool small = d.L <= kMmaLevels;
     for (int l = 0; small && l < d.L; ++l) small = order.D[l] <= 1000 && order.H[l] <= 1000 && order.W[l] <= 1000;
+    // point-column form (msda3d_pcm.hpp): one wave per 8 queries (2x2x2 sub-brick) and head; fp32 locations
+    if constexpr (sizeof(LT) == 4) {
+      if (lg >= 0 && small && pcm_ok(order, d) &&
+          !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA | TRANSOAR_MSDA3D_MMA_Q32))) {
+        ProfScope prof(TRANSOAR_PROF_FWD, st);
+        const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 16;
+        const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
+        const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
+        const PcmConst* cst = device_const(make_pcm_const(order));
+        if (cst == nullptr) return TRANSOAR_ERR_CONST;
+        hipLaunchKernelGGL((msda3d_fwd_pcm<VT, false>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
+                           v, lo, at, nullptr, nullptr, 0u, o, d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
+                           static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_wave), cst);
+        return static_cast<int>(hipGetLastError());
+      }
+    }
     if (lg >= 0 && order.enabled && small && d.C == 64 && d.P == 4 &&
         !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
       ProfScope prof(TRANSOAR_PROF_FWD, st);
@@ -266,6 +315,27 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
     else TRANSOAR_FWD(5);
 #undef TRANSOAR_FWD
   }
+  return static_cast<int>(hipGetLastError());
+}
+
+// forward with the module's sampling head fused into the gather's prologue (msda3d_pcm.hpp, FUSED)
+template <typename VT>
+static int launch_fwd_fused(const void* value, const void* proj, const float* ref, long ref_rows, void* out, const Dims& d,
+                            const int64_t* host_shapes, hipStream_t st) {
+  const BrickOrder order = make_order(host_shapes, d, d.Lq);
+  if (vec_lpv(d, sizeof(VT), 0) < 0 || !pcm_ok(order, d)) return TRANSOAR_ERR_DIM;
+  if (ref_rows != d.Lq && ref_rows != static_cast<long>(d.N) * d.Lq) return TRANSOAR_ERR_DIM;
+  ProfScope prof(TRANSOAR_PROF_FWD, st);
+  const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 16;
+  const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
+  const PcmConst* cst = device_const(make_pcm_const(order));
+  if (cst == nullptr) return TRANSOAR_ERR_CONST;
+  const unsigned ref_bstride = ref_rows == d.Lq ? 0u : static_cast<unsigned>(d.Lq) * d.L * 12u;
+  const long proj_bytes = static_cast<long>(d.N) * d.S * 4 * d.M * d.L * d.P * 2;
+  hipLaunchKernelGGL((msda3d_fwd_pcm<VT, true>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
+                     static_cast<const VT*>(value), nullptr, nullptr, static_cast<const unsigned short*>(proj), ref, ref_bstride,
+                     static_cast<VT*>(out), d.S, d.M, d.L, vbytes, static_cast<unsigned>(proj_bytes),
+                     static_cast<unsigned>(ref_rows * d.L * 12), static_cast<unsigned>(n_wave), cst);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -552,6 +622,20 @@ extern "C" int transoar_msda3d_forward(const void* value, const int64_t* spatial
                                         attn_weight, out, d, host_spatial_shapes, flags, st)));
 }
 
+extern "C" int transoar_msda3d_forward_fused(const void* value, const void* proj, const float* ref, long ref_rows,
+                                             void* out, int N, int S, int M, int C, int L, int P, int value_dtype,
+                                             const int64_t* host_spatial_shapes, void* hip_stream) {
+  if (!value || !proj || !ref || !out || !host_spatial_shapes) return TRANSOAR_ERR_NULL;
+  const Dims d{N, S, M, C, L, S, P};
+  const int rc = check_common(d, value_dtype, TRANSOAR_F32);
+  if (rc != TRANSOAR_OK) return rc;
+  if (value_dtype != TRANSOAR_BF16 && value_dtype != TRANSOAR_F16) return TRANSOAR_ERR_DTYPE;
+  if (misaligned(value) || misaligned(proj) || misaligned(ref) || misaligned(out)) return TRANSOAR_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (value_dtype == TRANSOAR_BF16) return launch_fwd_fused<bf16_t>(value, proj, ref, ref_rows, out, d, host_spatial_shapes, st);
+  return launch_fwd_fused<f16_t>(value, proj, ref, ref_rows, out, d, host_spatial_shapes, st);
+}
+
 extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
                                         const int64_t* level_start_index, const void* sampling_loc,
                                         const void* attn_weight, const void* grad_out,
@@ -631,4 +715,4 @@ extern "C" int transoar_msda3d_profile_read(double* total_ms, long* launches) {
   return rc;
 }
 
-extern "C" int transoar_msda3d_abi_version(void) { return 5; }
+extern "C" int transoar_msda3d_abi_version(void) { return 6; }

@@ -117,6 +117,35 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_forward_fused(value, spatial_shapes, proj, reference_points):
+    """Gather with the module's sampling head in its prologue (no reference counterpart as one call: it is
+    ops/modules/ms_deform_attn.py:114-136 -- softmax, ``ref + offsets / (W, H, D)``, MSDeformAttnFunction -- without
+    materialising sampling_locations / attention_weights).
+
+    value (N, S, M, C) bf16/f16; proj (N, S, 4*M*L*P) bf16 = [offsets (M, L, P, 3) | logits (M, L*P)] per query;
+    reference_points (1 or N, S, L, 3) fp32.  -> (N, S, M*C).  Queries are the pyramid's voxels (Lq == S)."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("proj", proj),
+                   ("reference_points", reference_points)])
+    _require(value.dim() == 4 and value.dtype in (torch.bfloat16, torch.float16), "value must be 16-bit (N, S, M, C)")
+    N, S, M, C = value.shape
+    L = spatial_shapes.size(0)
+    P = proj.size(-1) // (4 * M * L)
+    _require(proj.dtype == torch.bfloat16 and tuple(proj.shape) == (N, S, 4 * M * L * P), "proj must be bf16 (N, S, 4*M*L*P)")
+    _require(reference_points.dtype == torch.float32 and reference_points.dim() == 4 and
+             tuple(reference_points.shape[1:]) == (S, L, 3) and reference_points.size(0) in (1, N),
+             "reference_points must be fp32 (1 or N, S, L, 3)")
+    out = torch.empty((N, S, M * C), dtype=value.dtype, device=value.device)
+    _keep, host_ptr = _shapes_on_host(spatial_shapes)
+    _require(host_ptr is not None, "the fused gather needs the level shapes on the host (locality_hint)")
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _native.lib.transoar_msda3d_forward_fused(
+            value.data_ptr(), proj.data_ptr(), reference_points.data_ptr(), reference_points.size(0) * S,
+            out.data_ptr(), N, S, M, C, L, P, _DT[value.dtype], host_ptr, stream)
+    _native.check(rc, "transoar_msda3d_forward_fused")
+    return out
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]; replaces
