@@ -461,3 +461,91 @@ def test_matrix_core_gather_matches_per_corner_brick_kernel(MSDA):
             res.append(MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64))
         MSDA.flags = 0
         assert relerr(res[0], res[1]) <= TOL[vdt]
+
+
+def test_point_column_gather_matches_round2_kernels(MSDA):
+    """The default 16-bit forward is the point-column matrix-core gather (msda3d_pcm.hpp); flag 32 selects round 2's
+    32-query form, flag 16 the per-corner brick kernel.  All agree to output rounding on every element: flagship and
+    AMOS (3-level) pyramids, the refine block's pattern, its initial state, non-local and out-of-range locations."""
+    for geom in ("visceral", "amos"):
+        for dist in ("model", "init", "uniform", "oob"):
+            value, shapes, lsi, loc, attn = _full_size_case(geom, dist)
+            for vdt in (torch.bfloat16, torch.float16):
+                v = value[:1].to(vdt).contiguous()
+                res = []
+                for fl in (0, 32, 16):
+                    MSDA.flags = fl
+                    res.append(MSDA.ms_deform_attn_forward(v, shapes, lsi, loc[:1].contiguous(), attn[:1].contiguous(), 64))
+                MSDA.flags = 0
+                assert relerr(res[0], res[2]) <= TOL[vdt], (geom, dist, vdt)
+                assert relerr(res[1], res[2]) <= TOL[vdt], (geom, dist, vdt)
+
+
+@pytest.mark.parametrize("geom", ["visceral", "amos"])
+@pytest.mark.parametrize("vdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shared_ref", [True, False])
+def test_fused_head_gather_vs_c_oracle(MSDA, geom, vdt, shared_ref):
+    """transoar_msda3d_forward_fused (sampling head in the gather's prologue) at the full size: sampled queries against
+    the scalar C oracle fed with the locations / weights of the head's definition (softmax of the bf16 logits in fp32,
+    ref + bf16(offset / bf16(size)): tokens.sampling_head, itself tested against the eager chain), and every element
+    against the two-call path."""
+    from transoar_amd import tokens
+    levels = _inputs.VISCERAL_LEVELS if geom == "visceral" else _inputs.AMOS_LEVELS
+    value, shapes, lsi, _loc, _attn = _inputs.model_like_inputs(5, 2, levels, device="cuda")
+    N, S, M, C = value.shape
+    L, P = shapes.shape[0], 4
+    g = torch.Generator(device="cuda").manual_seed(29)
+    dirs = torch.tensor([(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (0, 1, 0), (1, 0, 0)], dtype=torch.float32, device="cuda")
+    step = torch.arange(1, P + 1, dtype=torch.float32, device="cuda")
+    off = (dirs[:, None, None, :] * step[None, None, :, None]).expand(M, L, P, 3)
+    off = off + 3.0 * (torch.rand(N, S, M, L, P, 3, device="cuda", generator=g) - 0.5)       # reaches outside the border bricks
+    logits = 2.0 * torch.randn(N, S, M, L * P, device="cuda", generator=g)
+    proj = torch.cat((off.reshape(N, S, -1), logits.reshape(N, S, -1)), -1).to(torch.bfloat16).contiguous()
+    ref = _inputs.reference_points(shapes.cpu()).to("cuda")[:, :, None, :].expand(1, S, L, 3)
+    if not shared_ref:
+        ref = ref.expand(N, S, L, 3) + 0.002 * torch.rand(N, S, L, 3, device="cuda", generator=g)
+    ref = ref.contiguous()
+    v = value.to(vdt)
+    loc, attn = tokens.sampling_head(proj, ref, shapes, M, L, P)
+    fused = MSDA.ms_deform_attn_forward_fused(v, shapes, proj, ref)
+    two = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, attn, 64)
+    assert relerr(fused, two) <= TOL[vdt]
+    edges = torch.cat([torch.arange(int(s), int(s) + 24) for s in lsi.tolist()] + [torch.arange(S - 24, S)])
+    pick = torch.cat([edges, torch.randint(0, S, (1100,), generator=torch.Generator().manual_seed(3))]).unique()
+    f = lambda t: t.float().cpu().numpy()
+    pc = pick.cuda()
+    want = c_oracle.forward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]), f(attn[:, pc]))
+    assert relerr(fused[:, pc], torch.from_numpy(want)) <= TOL[vdt]
+
+
+def test_module_uses_fused_gather_without_grad_and_matches_training_path():
+    """MSDeformAttn under bf16 autocast: with no gradient wanted the module runs the fused head + gather entry; its
+    output equals the training path's (sampling head kernel, then MSDeformAttnFunction) to bf16 rounding."""
+    from transoar_amd import MSDA as msda
+    from transoar_amd.ms_deform_attn import MSDeformAttn
+    torch.manual_seed(0)
+    levels = _inputs.AMOS_LEVELS
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    lsi = level_starts(shapes.cpu()).cuda()
+    S = int(shapes.prod(1).sum())
+    mod = MSDeformAttn(d_model=384, n_levels=len(levels), n_heads=6, n_points=4, use_cuda=True).cuda()
+    with torch.no_grad():       # generic offsets and weights instead of the initial state
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.05)
+    query = torch.randn(2, S, 384, device="cuda")
+    src = torch.randn(2, S, 384, device="cuda")
+    ref = _inputs.reference_points(shapes.cpu()).cuda()[:, :, None, :].expand(1, S, len(levels), 3).contiguous()
+    calls = []
+    orig = msda.ms_deform_attn_forward_fused
+    msda.ms_deform_attn_forward_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad():
+                y_eval = mod(query, ref, src, shapes, lsi)
+            assert calls, "the no-grad forward did not take the fused entry"
+            n_calls = len(calls)
+            y_train = mod(query.requires_grad_(), ref, src, shapes, lsi)
+            assert len(calls) == n_calls, "the training forward must not take the fused entry"
+    finally:
+        msda.ms_deform_attn_forward_fused = orig
+    assert relerr(y_eval, y_train.detach()) <= 2.0 ** -6

@@ -35,9 +35,11 @@ namespace transoar {
 
 constexpr int kPcmKB = 32;                // value rows per K-block
 constexpr int kPcmVP = 144;               // bytes per staged row: 128 + 16 (spreads the transposing reads over the banks)
-constexpr int kPcmWP = kPcmKB + 4;        // dwords per weight column: 32 K-slots, slot 32 = spare for entries outside the block
+constexpr int kPcmKW = 32;                // K-slots of a weight column: 32 (one staged block of rows) or 64 (two)
+constexpr int kPcmWP = kPcmKW + 4;        // dwords per weight column: 64 K-slots + 4 spares (one is used, by column: bank spread) for entries outside the block
 constexpr int kPcmBoxRows = 256;          // larger boxes: explicit (column, corner) slots instead (also 256 rows)
 constexpr int kPcmLevels = 4;
+constexpr int kPcmPU = 272, kPcmPF = 136;   // bytes per query of the staged parameter block (loc + attn fp32 / projection bf16), padded: the 8 queries start in different banks
 constexpr int kPcmSkip = 0x3fffffff;      // packed (d0, h0, w0) of a point that is skipped
 
 template <typename VT> struct PcmW;       // one trilinear weight -> (hi << 16) | lo, two 16-bit terms in the storage type
@@ -124,13 +126,13 @@ struct PcmConst {
 };
 
 template <typename VT, bool FUSED>
-__global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
+__global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
     const VT* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const unsigned short* __restrict__ proj, const float* __restrict__ ref, unsigned ref_bstride,
     VT* __restrict__ out, int S, int M, int L, unsigned value_bytes, unsigned param_bytes, unsigned aux_bytes,
     unsigned n_units, const PcmConst* __restrict__ cst) {
   const BrickOrder& order = cst->order;
-  constexpr int C = 64, KB = kPcmKB, VP = kPcmVP, WP = kPcmWP;
+  constexpr int C = 64, KB = kPcmKB, KW = kPcmKW, VP = kPcmVP, WP = kPcmWP;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];        // staged rows; parameter block and output rows alias it
   __shared__ __attribute__((aligned(16))) unsigned wbuf[32 * WP];            // [column][K-slot]: (hi << 16) | lo
 
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
         const unsigned off = (on && sq >= 0) ? __umul24(static_cast<unsigned>(sq), cols2) + in_row : 0xfffffff0u;
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(prs, off, 0, 0));
-        *reinterpret_cast<u32x2_t*>(vbuf + qq * 128 + r * 8) = v;
+        *reinterpret_cast<u32x2_t*>(vbuf + qq * kPcmPF + r * 8) = v;
       }
     } else {
       const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, static_cast<int>(param_bytes), 0x00020000);
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
         const unsigned aoff = (ok && !loc_piece) ? item * item_attn + (r - 12) * 16 : 0xfffffff0u;
         const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(lrs, loff, 0, 0);
         const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 0);
-        *reinterpret_cast<u32x4*>(vbuf + qq * 256 + r * 16) = loc_piece ? vl : va;
+        *reinterpret_cast<u32x4*>(vbuf + qq * kPcmPU + r * 16) = loc_piece ? vl : va;
       }
     }
   }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
     }
     if constexpr (FUSED) {
       const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ref), 0, static_cast<int>(aux_bytes), 0x00020000);
-      const unsigned short* pb = reinterpret_cast<const unsigned short*>(vbuf + q * 128);
+      const unsigned short* pb = reinterpret_cast<const unsigned short*>(vbuf + q * kPcmPF);
       const unsigned rrow = live ? (static_cast<unsigned>(s) - b * static_cast<unsigned>(S)) * L * 12u + b * ref_bstride : 0xfffffff0u;
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
       }
       fa[0] = e0 / sum; fa[1] = e1 / sum;
     } else {
-      const float* pb = reinterpret_cast<const float*>(vbuf + q * 256);
+      const float* pb = reinterpret_cast<const float*>(vbuf + q * kPcmPU);
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const int l = 2 * kh + pi;
@@ -353,14 +355,14 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
   for (int i = lane; i < 32 * WP / 2; i += 64) reinterpret_cast<uint2*>(wbuf)[i] = uint2{0u, 0u};
 
-  // rows [kb*KB, kb*KB + KB) of level l -> 4 x 16 bytes per lane (rows past the end, or outside the level: zeros).
-  // Lane i (and i + 32) computes the byte offset of row i; the 8 lanes that fetch a row get it through ds_bpermute.
-  const int st_row = lane >> 3, st_vec = lane & 7;
-  auto load_block = [&](auto lc, int kb, u32x4 (&pre)[4]) {
+  // Byte offsets of the 64 rows [k0, k0 + 64) of level l (lane i: row k0 + i); a row past the end or outside the
+  // level gets an offset past the buffer: it must read as zeros in ALL its 16-byte pieces (the piece offset is
+  // added later), hence 0xffffff00 and not the usual 0xfffffff0.
+  auto row_offsets = [&](auto lc, int k0) -> int {
     constexpr int l = decltype(lc)::value;
     const PcmBox bx = box[l];
     const int D = order.D[l], H = order.H[l], W = order.W[l], start = order.start[l];
-    const int r = kb * KB + n;
+    const int r = k0 + lane;
     int d, h, w;
     bool ok;
     if (mode[l] == 1) {
@@ -381,18 +383,23 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
     ok = ok && static_cast<unsigned>(d) < static_cast<unsigned>(D) && static_cast<unsigned>(h) < static_cast<unsigned>(H) &&
          static_cast<unsigned>(w) < static_cast<unsigned>(W);
     const int grow = start + __mul24(__mul24(d, H) + h, W) + w;
-    // a row outside the level (or past the end) must read as zeros in ALL its 16-byte pieces: the piece offset is added later
-    const int row_off = ok ? static_cast<int>(head_off + __umul24(static_cast<unsigned>(grow), row_bytes)) : static_cast<int>(0xffffff00u);
+    return ok ? static_cast<int>(head_off + __umul24(static_cast<unsigned>(grow), row_bytes)) : static_cast<int>(0xffffff00u);
+  };
+  // the 32 rows of one half of the 64: 4 x 16 bytes per lane; the 8 lanes that fetch a row get its offset through ds_bpermute
+  const int st_row = lane >> 3, st_vec = lane & 7;
+  auto issue_loads = [&](int row_off, int half, u32x4 (&pre)[4]) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const unsigned off = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute((it * 8 + st_row) * 4, row_off)) + st_vec * 16u;
+      const unsigned off = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute((half * 32 + it * 8 + st_row) * 4, row_off)) + st_vec * 16u;
       pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     }
   };
 
   u32x4 pre[4];
   bool have_pre = false;
+  int row_off = 0;
   unsigned* const wcol = wbuf + n * WP;
+  const int spare = KW + (n >> 3);            // the column's spare slot (entries outside the block): the 4 slots past the K-slots, so that the 32 columns' spares sit in 32 different banks
   static_for<0, kPcmLevels>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     if (mode[l] == 0) return;
@@ -403,18 +410,24 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
     int col[4];
     if (mode[l] == 1) {
       const int pd = pdhw[l];
-      const int d0 = (pd & 1023) - 1, h0 = ((pd >> 10) & 1023) - 1, w0 = ((pd >> 20) & 1023) - 1;
-      const int c0 = pd == kPcmSkip ? 0 : __mul24(__mul24(d0 - bx.bd + kh, bx.TH) + (h0 - bx.bh), bx.TW) + (w0 - bx.bw);
+      const int d1 = pd & 1023, h1 = (pd >> 10) & 1023, w1 = pd >> 20;        // d0 + 1, h0 + 1, w0 + 1
+      const int base = __mul24(__mul24(bx.bd + 1, bx.TH) + (bx.bh + 1), bx.TW) + (bx.bw + 1);
+      const int c0 = pd == kPcmSkip ? 0 : __mul24(__mul24(d1 + kh, bx.TH) + h1, bx.TW) + w1 - base;
       col[0] = c0; col[1] = c0 + 1; col[2] = c0 + bx.TW; col[3] = c0 + bx.TW + 1;
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) col[c] = n * 8 + kh * 4 + c;
     }
-    const int nblk = (R + KB - 1) / KB;
-    if (!have_pre) load_block(lc, 0, pre);
-    for (int kb = 0; kb < nblk; ++kb) {
-      const int k0 = kb * KB;
-      const int nch = (min(KB, R - k0) + 15) >> 4;          // 16-row chunks of this block: 1 or 2
+    const int nh = (R + KB - 1) / KB;                                     // halves of 32 rows
+    if (!have_pre) {
+      row_off = row_offsets(lc, 0);
+      issue_loads(row_off, 0, pre);
+    }
+    int wad[4];
+    for (int hb = 0; hb < nh; ++hb) {
+      const int half = hb & 1;                                            // which half of the 64 row offsets in row_off
+      const int sub = hb & (KW / KB - 1);                                 // which staged block of the weight column's K-slots
+      const int nch = (min(KB, R - hb * KB) + 15) >> 4;                   // 16-row chunks of this half: 1 or 2
       // ---- staged rows -> LDS
 #pragma unroll
       for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
@@ -422,28 +435,34 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
 #pragma unroll
         for (int it = 2; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
       }
-      // ---- prefetch the next block (of this level, or the first of the next one)
+      // ---- the lane's four entries for the 64 rows that start here: slot inside the block, or the spare slot
+      if (sub == 0) {
+        const int k0 = hb * KB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned t = static_cast<unsigned>(col[c] - k0);
+          wad[c] = t < static_cast<unsigned>(KW) ? static_cast<int>(t) : spare;
+          wcol[wad[c]] = wq[l][c];
+        }
+      }
+      // ---- prefetch the next half (of this level, or the first of the next one)
       have_pre = false;
-      if (kb + 1 < nblk) {
-        load_block(lc, kb + 1, pre);
+      if (hb + 1 < nh) {
+        if (half == 1) row_off = row_offsets(lc, (hb + 1) * KB);
+        issue_loads(row_off, half ^ 1, pre);
         have_pre = true;
       } else if constexpr (l + 1 < kPcmLevels) {
         if (mode[l + 1] != 0) {
-          load_block(IntC<l + 1>{}, 0, pre);
+          row_off = row_offsets(IntC<l + 1>{}, 0);
+          issue_loads(row_off, 0, pre);
           have_pre = true;
         }
       }
-      // ---- the lane's four entries: slot inside the block, or the spare slot
-      int wad[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        wad[c] = static_cast<int>(min(static_cast<unsigned>(col[c] - k0), static_cast<unsigned>(KB)));
-        wcol[wad[c]] = wq[l][c];
-      }
       // ---- 16-row chunks on the matrix cores
       for (int kc = 0; kc < nch; ++kc) {
-        const u32x4 p0 = *reinterpret_cast<const u32x4*>(wcol + kc * 16 + 8 * kh);
-        const u32x4 p1 = *reinterpret_cast<const u32x4*>(wcol + kc * 16 + 8 * kh + 4);
+        const unsigned* wp = wcol + sub * KB + kc * 16 + 8 * kh;
+        const u32x4 p0 = *reinterpret_cast<const u32x4*>(wp);
+        const u32x4 p1 = *reinterpret_cast<const u32x4*>(wp + 4);
         const u32x4 ahi{__builtin_amdgcn_perm(p0[1], p0[0], 0x07060302u), __builtin_amdgcn_perm(p0[3], p0[2], 0x07060302u),
                         __builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
         const u32x4 alo{__builtin_amdgcn_perm(p0[1], p0[0], 0x05040100u), __builtin_amdgcn_perm(p0[3], p0[2], 0x05040100u),
@@ -463,9 +482,11 @@ __global__ __launch_bounds__(64, 4) void msda3d_fwd_pcm(
         acc0 = Mma<VT>::mfma(wlo, v0, acc0);
         acc1 = Mma<VT>::mfma(wlo, v1, acc1);
       }
-      // ---- clear the entries again
+      // ---- clear the entries again when their 64 rows are done
+      if (sub == KW / KB - 1 || hb + 1 == nh) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) wcol[wad[c]] = 0u;
+        for (int c = 0; c < 4; ++c) wcol[wad[c]] = 0u;
+      }
     }
   });
 

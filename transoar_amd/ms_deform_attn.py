@@ -31,6 +31,16 @@ from .tokens import sampling_head as _sampling_head, sampling_head_usable as _sa
 _debug_core = None
 
 
+def _fused_usable(value, proj, reference_points, shapes, m, lv, pt, lq, s):
+    """The fused head + gather entry covers: no gradient wanted, 16-bit value with 64 channels per head, 4 points, at
+    most 4 levels, queries = the pyramid's voxels, host shapes available -- the refine block in evaluation."""
+    if torch.is_grad_enabled() and (value.requires_grad or proj.requires_grad):
+        return False
+    return (MSDA.locality_hint and not (MSDA.flags & 0x35) and lq == s and pt == 4 and lv <= 4
+            and value.dtype in (torch.bfloat16, torch.float16) and value.shape[-1] == 64 and value.is_contiguous()
+            and _sampling_head_usable(proj, reference_points, shapes, m, lv, pt))
+
+
 def register_debug_core(fn):
     """Install the callable used by ``MSDeformAttn(use_cuda=False)``:
     ``fn(value, spatial_shapes, sampling_locations, attention_weights) -> (N,Lq,M*C)``.
@@ -138,6 +148,12 @@ class MSDeformAttn(nn.Module):
         n_off = self.sampling_offsets.out_features
         proj = token_linear(query, torch.cat((self.sampling_offsets.weight, self.attention_weights.weight)),
                             torch.cat((self.sampling_offsets.bias, self.attention_weights.bias)))
+        if self.use_cuda and _fused_usable(value, proj, reference_points, input_spatial_shapes, m, lv, pt, lq, s):
+            # no gradient wanted (evaluation / inference): the sampling head runs in the gather's prologue and
+            # neither locations nor weights are materialised (transoar_msda3d_forward_fused)
+            sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, proj, reference_points, strict=False)
+            if sampled is not None:         # None: a form the fused kernel does not cover (e.g. level sizes > 1000)
+                return token_linear(sampled, self.output_proj.weight, self.output_proj.bias)
         if self.use_cuda and _sampling_head_usable(proj, reference_points, input_spatial_shapes, m, lv, pt):
             locations, weights = _sampling_head(proj, reference_points, input_spatial_shapes, m, lv, pt)
         else:

@@ -117,7 +117,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def ms_deform_attn_forward_fused(value, spatial_shapes, proj, reference_points):
+def ms_deform_attn_forward_fused(value, spatial_shapes, proj, reference_points, strict=True):
     """Gather with the module's sampling head in its prologue (no reference counterpart as one call: it is
     ops/modules/ms_deform_attn.py:114-136 -- softmax, ``ref + offsets / (W, H, D)``, MSDeformAttnFunction -- without
     materialising sampling_locations / attention_weights).
@@ -142,6 +142,8 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, proj, reference_points):
         rc = _native.lib.transoar_msda3d_forward_fused(
             value.data_ptr(), proj.data_ptr(), reference_points.data_ptr(), reference_points.size(0) * S,
             out.data_ptr(), N, S, M, C, L, P, _DT[value.dtype], host_ptr, stream)
+    if rc == -2 and not strict:           # TRANSOAR_ERR_DIM: not a form the fused kernel covers
+        return None
     _native.check(rc, "transoar_msda3d_forward_fused")
     return out
 
