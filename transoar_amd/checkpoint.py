@@ -69,6 +69,43 @@ def save_checkpoint(path, model, optimizer, scheduler, epoch, metric_max_val=0.0
     }, path)
 
 
+def load_optimizer_state(optimizer, state_dict):
+    """optimizer.load_state_dict that keeps what a captured step depends on (round-2 ADVICE).
+
+    ``Optimizer.load_state_dict`` replaces the param groups' hyper-parameters by the checkpoint's: for the capturable
+    AdamW of TrainStep(graph=True) that would turn the device-tensor learning rates into Python floats and switch
+    ``capturable`` off -- the captured update would raise, or (after capture) keep running on the old lr / moment /
+    step tensors.  Here the loaded values are copied INTO the existing tensors: lr tensors are filled in place, the
+    per-group flags capturable / fused / foreach / differentiable stay as constructed, and where per-parameter state
+    already exists (a warmed-up or captured optimizer) it is overwritten in place instead of being replaced."""
+    keep = ("capturable", "fused", "foreach", "differentiable")
+    before = [{k: g.get(k) for k in keep + ("lr",)} for g in optimizer.param_groups]
+    old_state = {p: dict(st) for p, st in optimizer.state.items()}
+    optimizer.load_state_dict(state_dict)
+    for g, b in zip(optimizer.param_groups, before):
+        for k in keep:
+            if b[k] is not None or k in g:
+                g[k] = b[k]
+        if torch.is_tensor(b["lr"]):
+            loaded = g["lr"]
+            b["lr"].fill_(float(loaded))
+            g["lr"] = b["lr"]
+        if "initial_lr" in g and torch.is_tensor(g["initial_lr"]):
+            g["initial_lr"] = float(g["initial_lr"])
+    for p, st in optimizer.state.items():
+        prev = old_state.get(p)
+        for k, v in list(st.items()):
+            if not torch.is_tensor(v):
+                continue
+            if prev is not None and torch.is_tensor(prev.get(k)):      # keep the tensor a captured graph knows
+                prev[k].copy_(v.to(prev[k].device))
+                st[k] = prev[k]
+            elif k == "step" and any(g.get("capturable") or g.get("fused") for g in optimizer.param_groups):
+                st[k] = v.to(p.device, torch.float32)                  # capturable / fused AdamW keep step on the device
+            else:
+                st[k] = v.to(p.device)
+
+
 def load_checkpoint(path, model, optimizer=None, scheduler=None, config=None, strict=True, map_location="cpu"):
     """Load a checkpoint written by the reference's Trainer (or by save_checkpoint).  -> (epoch, metric_max_val).
     Optimizer / scheduler states are restored when the objects are given; with ``config`` the scheduler's
@@ -79,7 +116,7 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, config=None, st
         raise KeyError("%s is not a transoar checkpoint: no %s" % (path, missing))
     model.load_state_dict(ckpt["model_state_dict"], strict=strict)
     if optimizer is not None and "optimizer_state_dict" in ckpt:
-        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        load_optimizer_state(optimizer, ckpt["optimizer_state_dict"])
     if scheduler is not None and "scheduler_state_dict" in ckpt:
         state = dict(ckpt["scheduler_state_dict"])
         if config is not None:

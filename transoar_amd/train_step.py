@@ -115,21 +115,28 @@ class TrainStep:
         # warm-up AND capture on one and the same side stream: autograd's AccumulateGrad nodes remember the
         # stream of the first backward; if the capture runs on another stream the engine inserts cross-stream
         # waits into the captured graph (the "AccumulateGrad node's stream does not match" warning)
+        # capture() must leave the model and the optimizer as it found them: the warm-up steps and the verification
+        # replay below update weights and moments when the AdamW update is part of the graph (round-2 ADVICE)
+        snap = self._snapshot() if self.capture_optimizer else None
         side = self.capture_stream()
         side.wait_stream(torch.cuda.current_stream())
+        eager_total = None
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                eager_total = self._eager_fwd_bwd(self._static_x, self._static_t)[0]
+            for k in range(warmup):
+                total = self._eager_fwd_bwd(self._static_x, self._static_t)[0]
+                if k == 0:
+                    eager_total = total          # the loss on the weights capture() was called with
+                    if self.reducer.active:
+                        self.reducer._end_first_step()      # dead parameters lose their bucket views before the capture (ADVICE)
                 if self.capture_optimizer:        # warm the optimizer's kernels (and allocate its state) outside the capture
                     self._clip()
                     self.optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # the first replay is checked against this eager loss (same inputs and weights; only the
-        # dropout masks differ) before the captured step is trusted: see _replay
-        self._expect_total = float(eager_total)
         from . import GRAPH_REPLAY_SAFE
         if not GRAPH_REPLAY_SAFE and not os.environ.get("TRANSOAR_TRUST_PACKET_CAPTURE"):
+            if snap is not None:
+                self._restore(snap)
             raise RuntimeError("HIP was initialised with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: this ROCm's pre-recorded "
                                "graph packets corrupt the replayed step (DESIGN.md section 8); export "
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or import transoar_amd before the first HIP call")
@@ -137,15 +144,66 @@ class TrainStep:
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
         mode = "thread_local" if self.reducer.active else "global"
-        with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
-            self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
-            if self.capture_optimizer:
-                self._clip()
-                self.optimizer.step()
+        try:
+            with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
+                self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
+                if self.capture_optimizer:
+                    self._clip()
+                    self.optimizer.step()
+        except Exception:
+            if snap is not None:
+                self._restore(snap)
+            raise
+        # ---- verification before the captured step is trusted: one replay on the capture batch, on the weights
+        # capture() was called with, against the eager loss on those weights (only the dropout masks differ)
+        if snap is not None:
+            self._restore(snap)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = float(self._static_total)
+        expect = float(eager_total) if eager_total is not None else got
+        if snap is not None:
+            self._restore(snap)          # undo the verification replay's update
+        if not (got == got and abs(got - expect) <= 0.2 * abs(expect) + 1e-3):
+            self.drop_graph()
+            raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
+        self._expect_total = None
         self._graph = graph
         # TRANSOAR_GRAPH_SERIALIZE=1: never launch the graph again before its previous launch has finished on the GPU
         self._replay_done = torch.cuda.Event() if os.environ.get("TRANSOAR_GRAPH_SERIALIZE") else None
         return self
+
+    def _snapshot(self):
+        """Copies of every parameter and of the optimizer's state tensors (None where the state does not exist yet)."""
+        params = [p.detach().clone() for p in self.model.parameters()]
+        state = []
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                st = self.optimizer.state.get(p)
+                state.append(None if not st else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()})
+        return params, state
+
+    def _restore(self, snap):
+        """In place (the captured graph holds the addresses): parameters back to the snapshot, optimizer state back to
+        the snapshot or -- where it was created after the snapshot -- to its initial zeros."""
+        params, state = snap
+        with torch.no_grad():
+            for p, c in zip(self.model.parameters(), params):
+                p.copy_(c)
+            i = 0
+            for group in self.optimizer.param_groups:
+                for p in group["params"]:
+                    st, old = self.optimizer.state.get(p), state[i]
+                    i += 1
+                    if not st:
+                        continue
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if old is None:
+                                v.zero_()
+                            else:
+                                v.copy_(old[k])
+        self.model.zero_grad(set_to_none=False)
 
     def capture_stream(self):
         """The side stream every eager step before a capture should run on (see capture())."""
