@@ -247,7 +247,7 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     #   pred_boxes (values in [0,1])        max abs error   <= 5e-3      (observed 1.4e-3)
     #   pred_logits                          max error       <= 0.1 of the largest |logit| + 2e-2 (observed 0.053; rms 0.013)
     #   each of the 11 loss scalars          relative error  <= 1e-2      (observed 2e-3, same matches in both passes)
-    #   parameter gradients, relative L2     median <= 6e-2 (observed 0.03), 90 % <= 0.4 (observed 0.26), all <= 2.5
+    #   parameter gradients, relative L2     median <= 6e-2 (observed 0.03), 90 % <= 0.4 (observed 0.26), each <= 0.6 except two named
     #                                        (observed 1.14 on the first InstanceNorm's bias)
     # (the first encoder convolutions sit behind 12 InstanceNorms: their gradients are ill-conditioned --
     # >10 % checksum drift between two fp32 CPU runs, tests/test_data_parallel.py -- hence the tail bound)
@@ -268,7 +268,12 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
         rel[len(rel) // 2][0], rel[int(0.9 * len(rel))][0], rel[-1][0], rel[-1][1]))
     assert rel[len(rel) // 2][0] <= 6e-2, rel[len(rel) // 2]
     assert rel[int(0.9 * len(rel))][0] <= 0.4, rel[int(0.9 * len(rel)):][:5]
-    assert rel[-1][0] <= 2.5, rel[-3:]
+    # per-tensor bound (round-2 VERDICT weak #2): every tensor <= 0.6 (observed <= 0.39) except the two named ones -- the
+    # affine parameters of the FIRST InstanceNorm, behind all 12 norm layers of the encoder, where two fp32 runs already
+    # differ by > 10 % (tests/test_data_parallel.py): observed 0.58 / 1.14
+    ill = {"_backbone._encoder._stages.0._block.1.weight": 2.5, "_backbone._encoder._stages.0._block.1.bias": 2.5}
+    over = [(r, n) for r, n in rel if r > ill.get(n, 0.6)]
+    assert not over, over
 
 
 @pytest.mark.parametrize("device", _device_params())

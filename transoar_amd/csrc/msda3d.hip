@@ -151,7 +151,7 @@ static inline size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(
 // are the suspect of the corrupted replays of DESIGN.md section 8).  One immutable copy per distinct content and
 // device, made on first use -- a synchronous hipMalloc + hipMemcpy, so first use must be an eager call (the
 // training step always runs eagerly before it is captured); returns nullptr if that is not possible.
-static const void* device_const(const void* host, size_t bytes) {
+static const void* device_const(const void* host, size_t bytes, hipStream_t st) {
   static std::mutex mu;
   static std::map<std::pair<int, std::string>, void*> cache;
   int dev = 0;
@@ -160,6 +160,11 @@ static const void* device_const(const void* host, size_t bytes) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
+  // not cached yet: making the copy needs hipMalloc + a synchronous hipMemcpy, neither of which may run while `st`
+  // is being captured (in global capture mode the hipMalloc alone invalidates the capture): refuse instead
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (cache.size() >= 256) return nullptr;            // bounded: a few entries per (device, pyramid shape) are expected
   void* p = nullptr;
   if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
   if (hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -169,8 +174,8 @@ static const void* device_const(const void* host, size_t bytes) {
   cache[key] = p;
   return p;
 }
-template <typename T> static const T* device_const(const T& v) {
-  return static_cast<const T*>(device_const(&v, sizeof(T)));
+template <typename T> static const T* device_const(const T& v, hipStream_t st) {
+  return static_cast<const T*>(device_const(&v, sizeof(T), st));
 }
 
 // Can the vector kernels run this problem?  (32-bit byte offsets into value,
@@ -271,7 +276,7 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
         const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 16;
         const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
         const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
-        const PcmConst* cst = device_const(make_pcm_const(order));
+        const PcmConst* cst = device_const(make_pcm_const(order), st);
         if (cst == nullptr) return TRANSOAR_ERR_CONST;
         hipLaunchKernelGGL((msda3d_fwd_pcm<VT, false>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                            v, lo, at, nullptr, nullptr, 0u, o, d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
@@ -284,7 +289,7 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
       ProfScope prof(TRANSOAR_PROF_FWD, st);
       const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 4;
       const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
-      const BrickOrder* order_d = device_const(order);
+      const BrickOrder* order_d = device_const(order, st);
       if (order_d == nullptr) return TRANSOAR_ERR_CONST;
       hipLaunchKernelGGL((msda3d_fwd_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                          v, lo, at, o, d.S, d.M, d.L, vbytes, n_wave, order_d);
@@ -328,7 +333,7 @@ static int launch_fwd_fused(const void* value, const void* proj, const float* re
   ProfScope prof(TRANSOAR_PROF_FWD, st);
   const long n_wave = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 16;
   const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
-  const PcmConst* cst = device_const(make_pcm_const(order));
+  const PcmConst* cst = device_const(make_pcm_const(order), st);
   if (cst == nullptr) return TRANSOAR_ERR_CONST;
   const unsigned ref_bstride = ref_rows == d.Lq ? 0u : static_cast<unsigned>(d.Lq) * d.L * 12u;
   const long proj_bytes = static_cast<long>(d.N) * d.S * 4 * d.M * d.L * d.P * 2;
@@ -422,7 +427,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
       ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
       const long n_wave = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M * 4;
-      const BrickOrder* order_d = device_const(q_order);
+      const BrickOrder* order_d = device_const(q_order, st);
       if (order_d == nullptr) return TRANSOAR_ERR_CONST;
       hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                          v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes,
@@ -495,8 +500,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       const int cell_chunk = mma ? kCmCellChunk : kCellChunk;
       cl.chunks_per_slab = static_cast<int>((static_cast<long>(d.Lq) * d.P * coarse_levels + cell_chunk - 1) / cell_chunk) + 1;
       const int fine_bricks = r_order.pad_start[cl.first] >> 7;
-      const BrickOrder* r_order_d = device_const(r_order);
-      const CoarseLevels* cl_d = device_const(cl);
+      const BrickOrder* r_order_d = device_const(r_order, st);
+      const CoarseLevels* cl_d = device_const(cl, st);
       if (r_order_d == nullptr || cl_d == nullptr) return TRANSOAR_ERR_CONST;
       float* scratch = reinterpret_cast<float*>(ws + w.coarse);
       const long scratch_elems = static_cast<long>(d.N) * cl.rows * d.M * kTileC;
