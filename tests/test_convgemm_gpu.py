@@ -1,0 +1,60 @@
+"""GPU: the LDS-tiled implicit-GEMM convolution kernels (csrc/conv_gemm.hip) against PyTorch's fp32 convolution on the
+same bf16-rounded inputs: forward (stride 1 and 2, bias, split-K), data gradient (stride 1: mirrored taps; stride 2:
+eight parity-class launches, with and without the shared fp32 accumulator), weight gradient, and the token-projection
+weight gradient as the one-tap case.  Tolerances: bf16 outputs 2^-7 of the tensor's max; fp32 weight gradients 2e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-300)
+
+
+CASES = [  # N, Cin, Cout, D, H, W, stride, bias  -- odd sizes, partial tiles on rows and channels, K steps straddling taps
+    (2, 48, 48, 6, 10, 16, 1, False), (1, 24, 48, 8, 8, 16, 2, False), (2, 48, 96, 4, 6, 16, 2, False),
+    (1, 96, 96, 5, 5, 8, 1, False), (1, 96, 384, 4, 4, 8, 1, True), (2, 8, 40, 3, 7, 24, 1, True),
+    (1, 192, 136, 3, 5, 7, 1, True), (1, 200, 64, 5, 7, 9, 2, False), (1, 384, 768, 2, 4, 4, 2, False),
+    (1, 768, 768, 2, 2, 4, 1, False), (2, 96, 192, 6, 6, 8, 2, False), (1, 56, 72, 7, 9, 11, 2, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("split", [None, 1, 3])
+def test_conv_gemm_forward_dgrad_wgrad(case, split):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    n, ci, co, d, h, w, s, bias = case
+    torch.manual_seed(ci * 1000 + co)
+    x = torch.randn(n, ci, d, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    wt = (torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.1).to(torch.bfloat16).float()
+    b = torch.randn(co, device="cuda") if bias else None
+    xr, wr = x.float().requires_grad_(), wt.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, b, stride=s, padding=1)
+    if True:
+        y = G.conv_forward(x, G.pack_fwd(wt), b, s, split=split)
+        assert y.is_contiguous(memory_format=torch.channels_last_3d) and tuple(y.shape) == tuple(yr.shape)
+        assert relerr(y, yr) <= 2.0 ** -7
+        g = torch.randn_like(yr).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+        yr.backward(g.float())
+        gx = G.conv_dgrad(g, G.pack_dgrad(wt), s, (d, h, w), split=split)
+        assert relerr(gx, xr.grad) <= 2.0 ** -7
+    gw = G.conv_wgrad(x, g, s)
+    assert relerr(gw, wr.grad) <= 2e-3
+
+
+@pytest.mark.parametrize("t,k,nn_", [(1000, 384, 384), (4097, 384, 1024), (333, 1024, 384), (5000, 48, 64)])
+def test_linear_wgrad_is_the_one_tap_case(t, k, nn_):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    torch.manual_seed(t)
+    x = torch.randn(t, k, device="cuda").to(torch.bfloat16)
+    gy = torch.randn(t, nn_, device="cuda").to(torch.bfloat16)
+    want = gy.float().t() @ x.float()
+    got = G.linear_wgrad(x, gy)
+    assert relerr(got, want) <= 2e-3

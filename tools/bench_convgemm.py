@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Per-layer timing of the LDS-tiled implicit-GEMM convolution kernels (csrc/conv_gemm.hip) against MIOpen/CK (tuned
+find-db, NDHWC operands) on the backbone's real shapes, batch 2, bf16: forward, data gradient, weight gradient."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_db"))
+import torch
+import torch.nn.functional as F
+from transoar_amd import conv_gemm as G
+
+LAYERS = [  # name, Cin, Cout, D, H, W (input), stride
+    ("s1c1", 24, 48, 160, 160, 256, 2), ("s1c2", 48, 48, 80, 80, 128, 1), ("s2c1", 48, 96, 80, 80, 128, 2),
+    ("s2c2", 96, 96, 40, 40, 64, 1), ("s3c1", 96, 192, 40, 40, 64, 2), ("s3c2", 192, 192, 20, 20, 32, 1),
+    ("s4c1", 192, 384, 20, 20, 32, 2), ("s4c2", 384, 384, 10, 10, 16, 1), ("s5c1", 384, 768, 10, 10, 16, 2),
+    ("s5c2", 768, 768, 5, 5, 8, 1), ("outP2", 96, 384, 40, 40, 64, 1), ("outP3", 192, 384, 20, 20, 32, 1),
+    ("outP4", 384, 384, 10, 10, 16, 1), ("outP5", 384, 384, 5, 5, 8, 1),
+]
+
+
+def t_ms(fn, n=7):
+    fn(); fn(); torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for i in range(n):
+        fn(); ev[i + 1].record()
+    torch.cuda.synchronize()
+    return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2]
+
+
+only = [a for a in sys.argv[1:] if not a.startswith("-")]
+with_miopen = "--no-miopen" not in sys.argv
+for name, ci, co, d, h, w, s in LAYERS:
+    if only and name not in only:
+        continue
+    x = torch.randn(2, ci, d, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    wt = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
+    wk, wkt = G.pack_fwd(wt), G.pack_dgrad(wt)
+    res = {"layer": name, "shape": [ci, co, d, h, w, s]}
+    y = G.conv_forward(x, wk, None, s)
+    gy = torch.randn_like(y)
+    res["own_fwd"] = round(t_ms(lambda: G.conv_forward(x, wk, None, s)), 3)
+    res["own_dgrad"] = round(t_ms(lambda: G.conv_dgrad(gy, wkt, s, (d, h, w))), 3)
+    if x.shape[0] * y.shape[2] * y.shape[3] * y.shape[4] < (1 << 21):
+        res["own_wgrad"] = round(t_ms(lambda: G.conv_wgrad(x, gy, s)), 3)
+    flop = 2 * 27 * ci * co * y.shape[2] * y.shape[3] * y.shape[4] * 2
+    res["fwd_TFs"] = round(flop / res["own_fwd"] / 1e9, 1)
+    if with_miopen:
+        xn = x.detach().requires_grad_()
+        wn = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d).requires_grad_()
+        res["miopen_fwd"] = round(t_ms(lambda: F.conv3d(xn, wn, stride=s, padding=1)), 3)
+        yn = F.conv3d(xn, wn, stride=s, padding=1)
+        gn = torch.randn_like(yn)
+        res["miopen_dgrad"] = round(t_ms(lambda: torch.autograd.grad(yn, (xn,), gn, retain_graph=True)), 3)
+        res["miopen_wgrad"] = round(t_ms(lambda: torch.autograd.grad(yn, (wn,), gn, retain_graph=True)), 3)
+    print(json.dumps(res), flush=True)
+    del x, y, gy

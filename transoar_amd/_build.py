@@ -22,6 +22,7 @@ LIBS = {
     "libtransoar_rows.so": ["rows.hip"],
     "libtransoar_tokens.so": ["tokens.hip"],
     "libtransoar_gemm.so": ["gemm.hip"],
+    "libtransoar_convgemm.so": ["conv_gemm.hip"],
 }
 
 

@@ -156,7 +156,8 @@ class Decoder(nn.Module):
         self._out = nn.ModuleList()
         for n, stage in enumerate(self._required_stages):
             cout = enc_channels[0] if (self._seg_proxy and n == 0) else fpn
-            self._out.append(nn.Conv3d(lateral_out[stage - first], cout, kernel_size=3, padding=1))
+            # nn.Conv3d's parameters and state-dict keys; bf16 GPU path on the implicit-GEMM kernels (conv_gemm.hip)
+            self._out.append(Conv3dK3(lateral_out[stage - first], cout, kernel_size=3, padding=1))
 
         # top-down path, coarsest first
         self._up = nn.ModuleList()

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import _native  # noqa: F401  (torch's HIP runtime first)
 from . import rows as _rows
+from . import conv_gemm as _cg
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
@@ -239,6 +240,9 @@ class _Conv3dK3(torch.autograd.Function):
                 x8 = torch.zeros((n, d, h, w, 8), dtype=torch.bfloat16, device=x.device)
                 x8[..., 0] = xb.view(n, d, h, w)
                 y = conv3d_k3_forward(x8.permute(0, 4, 1, 2, 3), _pack_taps(w8), b32, stride)
+        elif _use_gemm(ci, weight.shape[0], stride):
+            # 48 channels and up (and the strided 24 -> 48 layer): LDS-tiled implicit GEMM (csrc/conv_gemm.hip)
+            y = _cg.conv_forward(xb, _cg.pack_fwd(weight), bias.float() if bias is not None else None, stride)
         else:
             y = conv3d_k3_forward(xb, _pack_taps(weight), bias.float() if bias is not None else None, stride)
         ctx.save_for_backward(xb, weight)
@@ -259,9 +263,12 @@ class _Conv3dK3(torch.autograd.Function):
         gyb = _as_ndhwc(gy)
         gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        hip_x = need_x and (ctx.stride == 1 or _Conv3dK3.hip_dgrad_strided)
+        gemm = _use_gemm(xb.shape[1], weight.shape[0], ctx.stride)
+        hip_x = need_x and (gemm or ctx.stride == 1 or _Conv3dK3.hip_dgrad_strided)
         hip_w = need_w and _Conv3dK3.hip_wgrad
-        if hip_x:
+        if hip_x and gemm:
+            gx = _cg.conv_dgrad(gyb, _cg.pack_dgrad(weight), ctx.stride, tuple(xb.shape[2:]))
+        elif hip_x:
             # data gradient = convolution of dy with the flipped, in/out-swapped filter
             wt = weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, weight.shape[1], weight.shape[0])
             gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
@@ -269,6 +276,8 @@ class _Conv3dK3(torch.autograd.Function):
             gw, hip_w = conv3d_c1_wgrad(xb, gyb).to(weight.dtype), True       # one input channel: MFMA over voxel chunks
         elif need_w and ctx.stride == 1 and lds_wgrad_supported(xb, gyb):
             gw, hip_w = conv3d_k3_wgrad_lds(xb, gyb).to(weight.dtype), True   # few channels, 10^7 voxels: LDS-transposed MFMA
+        elif need_w and xb.shape[1] % 8 == 0 and gyb.numel() // gyb.shape[1] < (1 << 21):
+            gw, hip_w = _cg.conv_wgrad(xb, gyb, ctx.stride).to(weight.dtype), True     # voxel-major GEMM with transposing LDS reads
         elif hip_w:
             gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
         if (need_x and not hip_x) or (need_w and not hip_w):
@@ -295,6 +304,12 @@ class _Conv3dK3(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+def _use_gemm(cin, cout, stride):
+    """Which forward / data-gradient kernel family: the LDS-tiled implicit GEMM from 48 channels up and for every strided
+    layer with >= 8 input channels; the halo-tile / direct kernels of conv3d.hip for the full-resolution 24-channel layers."""
+    return cin >= 8 and cin % 8 == 0 and cout % 8 == 0 and (stride == 2 or cin > 24 or cout > 32)
+
+
 def hip_conv_supported(x, conv):
     return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
@@ -310,7 +325,7 @@ class Conv3dK3(nn.Conv3d):
     ``min_voxels``: below this many output voxels the grid is too small for the
     v1 kernel (no split-K) and the layer stays on MIOpen."""
     enabled = True
-    min_voxels = 1 << 20
+    min_voxels = 0          # every 3x3x3 layer of the model runs on the hand-written kernels (conv3d.hip, conv_gemm.hip)
     # channels-last maps stay channels-last into the stock (MIOpen) convolutions: its CK solvers are NDHWC natively,
     # and miopen_db/ holds find-db entries for the NDHWC keys of every layer of the flagship model (52.2 -> 51.4 ms
     # per step against converting to NCDHW first).  TRANSOAR_NDHWC_ALL=0: convert (the round-1 behaviour).

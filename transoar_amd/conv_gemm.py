@@ -1,0 +1,171 @@
+"""ctypes binding and autograd shim of the LDS-tiled implicit-GEMM convolution kernels (C ABI:
+include/transoar_convgemm.h): the 3x3x3 convolutions of the encoder stages from 48 channels up and of the FPN `out`
+layers (encoder_blocks.py:28-51, attn_fpn.py:65-73,126), forward, data gradient (stride 1: one launch with the
+mirrored tap list; stride 2: eight launches, one per parity class of the dx voxels) and weight gradient -- and the
+weight gradient of a token projection as the one-tap case.  No fallback: the library must be built."""
+import ctypes
+import os
+
+import torch
+
+from . import _native  # noqa: F401  (torch's HIP runtime first)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libtransoar_convgemm.so")
+ABI_VERSION = 1
+CL3D = torch.channels_last_3d
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise _native.NativeLibraryError("%s is not built (python transoar_amd/_build.py)" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    i, p, u = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint
+    lib.transoar_conv3d_igemm.restype = i
+    lib.transoar_conv3d_igemm.argtypes = [p] * 5 + [i] * 17 + [u] * 3 + [i, i, p]
+    lib.transoar_conv3d_finish.restype = i
+    lib.transoar_conv3d_finish.argtypes = [p, p, p, ctypes.c_long, i, i, p]
+    lib.transoar_conv3d_wgrad.restype = i
+    lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
+    lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
+    lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i]
+    lib.transoar_convgemm_abi_version.restype = i
+    if lib.transoar_convgemm_abi_version() != ABI_VERSION:
+        raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
+    return lib
+
+
+lib = _load()
+
+
+def _taps(entries):
+    """[(delta, t), ...] -> packed per-axis tap list (include/transoar_convgemm.h)."""
+    v = len(entries)
+    for e, (delta, t) in enumerate(entries):
+        v |= ((delta + 1) << (2 + 4 * e)) | (t << (4 + 4 * e))
+    return v
+
+
+TAPS_FWD = _taps([(-1, 0), (0, 1), (1, 2)])        # source = s*m + t - 1
+TAPS_DGRAD1 = _taps([(1, 0), (0, 1), (-1, 2)])     # source = m + 1 - t
+TAPS_PARITY = (_taps([(0, 1)]), _taps([(1, 0), (0, 2)]))     # dx voxel 2m + p: p = 0 sees tap 1 of dy m; p = 1 taps 0, 2 of dy m+1, m
+TAPS_ONE = _taps([(0, 1)])
+
+# launches with fewer output tiles than this split their K steps (fp32 atomics + a cast pass)
+SPLIT_BELOW_TILES = 384
+WGRAD_BLOCKS = 2048
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack_fwd(weight):
+    """(Cout, Cin, 3,3,3) -> (27, Cout, Cin) bf16."""
+    co, ci = weight.shape[:2]
+    return weight.permute(2, 3, 4, 0, 1).reshape(27, co, ci).to(torch.bfloat16).contiguous()
+
+
+def pack_dgrad(weight):
+    """(Cout, Cin, 3,3,3) -> (27, Cin, Cout) bf16: the data gradient contracts over Cout."""
+    co, ci = weight.shape[:2]
+    return weight.permute(2, 3, 4, 1, 0).reshape(27, ci, co).to(torch.bfloat16).contiguous()
+
+
+def _split_for(tiles, k_steps):
+    if tiles >= SPLIT_BELOW_TILES:
+        return 1
+    return max(1, min((SPLIT_BELOW_TILES + tiles - 1) // tiles, k_steps // 4, 16))
+
+
+def _tiles(rows, cout):
+    bn = 64 if cout <= 64 else 128
+    return ((rows + 127) // 128) * ((cout + bn - 1) // bn)
+
+
+def _igemm(x, wk, bias, out, src_dims, cin, cout, m_dims, src_stride, out_dims, out_stride, parity, taps, n, split, classes=0):
+    """One launch of transoar_conv3d_igemm (+ the summing / cast pass when split > 1); `out` is the whole output map."""
+    b = bias.data_ptr() if bias is not None else None
+    with torch.cuda.device(x.device):
+        if split > 1:
+            rows_out = n * out_dims[0] * out_dims[1] * out_dims[2]
+            part = torch.empty((split, rows_out, cout), dtype=torch.float32, device=x.device)      # written completely
+            _check(lib.transoar_conv3d_igemm(x.data_ptr(), wk.data_ptr(), None, None, part.data_ptr(), n, *src_dims, cin, cout,
+                                             *m_dims, src_stride, *out_dims, out_stride, *parity, *taps, split, classes, _stream()),
+                   "transoar_conv3d_igemm")
+            _check(lib.transoar_conv3d_finish(part.data_ptr(), b, out.data_ptr(), rows_out, cout, split, _stream()),
+                   "transoar_conv3d_finish")
+        else:
+            _check(lib.transoar_conv3d_igemm(x.data_ptr(), wk.data_ptr(), b, out.data_ptr(), None, n, *src_dims, cin, cout,
+                                             *m_dims, src_stride, *out_dims, out_stride, *parity, *taps, 1, classes, _stream()),
+                   "transoar_conv3d_igemm")
+
+
+def conv_forward(x, wk, bias, stride, split=None):
+    """x (N, Cin, D, H, W) NDHWC bf16, wk (27, Cout, Cin) bf16, bias fp32 or None -> (N, Cout, Do, Ho, Wo) NDHWC bf16."""
+    n, ci, d, h, w = x.shape
+    co = wk.shape[1]
+    od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, co, od, oh, ow), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
+    if split is None:
+        split = _split_for(_tiles(n * od * oh * ow, co), (27 * ci + 63) // 64)
+    _igemm(x, wk, bias, y, (d, h, w), ci, co, (od, oh, ow), stride, (od, oh, ow), 1, (0, 0, 0), (TAPS_FWD,) * 3, n, split)
+    return y
+
+
+def conv_dgrad(gy, wkt, stride, in_dims, split=None):
+    """gy (N, Cout, Do, Ho, Wo) NDHWC bf16, wkt (27, Cin, Cout) bf16 -> dx (N, Cin, D, H, W) NDHWC bf16."""
+    n, co, od, oh, ow = gy.shape
+    ci = wkt.shape[1]
+    d, h, w = in_dims
+    gx = torch.empty((n, ci, d, h, w), dtype=torch.bfloat16, device=gy.device, memory_format=CL3D)
+    if stride == 1:
+        if split is None:
+            split = _split_for(_tiles(n * d * h * w, ci), (27 * co + 63) // 64)
+        _igemm(gy, wkt, None, gx, (od, oh, ow), co, ci, (d, h, w), 1, (d, h, w), 1, (0, 0, 0), (TAPS_DGRAD1,) * 3, n, split)
+        return gx
+    # stride 2: the eight parity classes (pd, ph, pw) of the dx voxels in one launch: 1, 2, 4 or 8 taps each
+    if split is None:
+        split = _split_for(_tiles(n * d * h * w, ci), (8 * co + 63) // 64)      # K steps of the eight-tap class
+    _igemm(gy, wkt, None, gx, (od, oh, ow), co, ci, (1, 1, 1), 1, (d, h, w), 2, (0, 0, 0), (TAPS_ONE,) * 3, n, split, classes=1)
+    return gx
+
+
+def _wgrad(x2, gy2, geom, taps, taps_out, out_shape):
+    n, sd, sh, sw, ci, co, md, mh, mw, stride = geom
+    nt = 1
+    for t in taps:
+        nt *= t & 3
+    bt = 64 if (ci <= 64 and co <= 64) else 128
+    tiles = nt * ((co + bt - 1) // bt) * ((ci + bt - 1) // bt)
+    rows = n * md * mh * mw
+    chunks = max(1, min(WGRAD_BLOCKS // tiles, rows // 256 if rows >= 256 else 1))
+    part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks), dtype=torch.float32, device=x2.device)
+    dw = torch.empty(out_shape, dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        _check(lib.transoar_conv3d_wgrad(gy2.data_ptr(), x2.data_ptr(), part.data_ptr(), dw.data_ptr(), n, sd, sh, sw, ci, co, md, mh, mw,
+                                         stride, *taps, chunks, taps_out, _stream()), "transoar_conv3d_wgrad")
+    return dw
+
+
+def conv_wgrad(x, gy, stride):
+    """x (N, Cin, D, H, W), gy (N, Cout, Do, Ho, Wo) NDHWC bf16 -> dW (Cout, Cin, 3, 3, 3) fp32."""
+    n, ci, d, h, w = x.shape
+    co, od, oh, ow = gy.shape[1:]
+    return _wgrad(x, gy, (n, d, h, w, ci, co, od, oh, ow, stride), (TAPS_FWD,) * 3, 27, (co, ci, 3, 3, 3))
+
+
+def linear_wgrad(x, gy):
+    """x (T, K), gy (T, N) bf16 contiguous -> dW (N, K) fp32 = gy^T x (the one-tap case)."""
+    t, k = x.shape
+    nn_ = gy.shape[1]
+    return _wgrad(x, gy, (1, 1, 1, t, k, nn_, 1, 1, t, 1), (TAPS_ONE,) * 3, 1, (nn_, k))
+
+
+def supported(cin, cout, rows):
+    return cin % 8 == 0 and cout % 8 == 0 and cin >= 8 and rows < (1 << 21)

@@ -1,0 +1,595 @@
+// 3x3x3 convolutions of the deep encoder stages and the FPN as an LDS-tiled implicit GEMM on the matrix cores (gfx950).
+//
+// Reference layers: EncoderCnnBlock (backbones/encoder_blocks.py:28-51: Conv3d(3, stride s, pad 1, no bias), stages
+// 1-5 at 48..768 channels) and the FPN `out` convolutions (backbones/attn_fpn.py:65-73,126: Conv3d(3, pad 1) + bias,
+// 96..384 -> 384).  conv3d.hip covers the full-resolution layers (<= 32 channels, halo tile in LDS); this file covers
+// everything from 48 channels up, forward and both gradients, so that no 3^3 convolution is left to MIOpen:
+//
+//   transoar_conv3d_igemm   Y[m][n] = sum_{tap, c} X[src(m, tap)][c] * Wk[tap][n][c] (+ bias[n])
+//       rows m = voxels of a "row space" (MD, MH, MW) per batch element, src(m, tap) = stride * m + delta(tap) in the
+//       source map, out-of-range sources read as zeros (the padding), the result row goes to voxel
+//       out_stride * m + out_parity of the output map.  One kernel, three uses:
+//         forward          row space = output map, stride 1 or 2, taps = all 27 with delta = t - 1
+//         data gradient    of a stride-1 layer: the same with the flipped, in/out-swapped filter (host packs it)
+//         data gradient    of a stride-2 layer: eight launches, one per parity class (pd, ph, pw) of the dx voxels --
+//                          a dx voxel of even coordinate sees tap 1 of dy voxel x/2, one of odd coordinate taps 0
+//                          and 2 of dy voxels (x+1)/2 and (x-1)/2: row space = the class's voxels, 1/2/4/8 taps,
+//                          source = dy at stride 1, output rows strided by 2 into dx
+//   transoar_conv3d_wgrad   dW[tap][co][ci] = sum_m dY[m][co] * X[src(m, tap)][ci]  (msda-style "TN" GEMM: both
+//       operands have the contraction axis (voxels) as their slow axis; tiles are staged K-major and read with the
+//       transposing ds_read_b64_tr_b16), split over voxel ranges, fp32 atomics into dW.  With taps = 1 and no
+//       shift it is the weight gradient of a token projection (dW = dY^T X, decoder_blocks.py:157-174).
+//
+// GEMM machinery = gemm.hip's: 256 threads = 2 x 2 waves, block tile 128 x 128, K step 64, v_mfma_f32_32x32x16_bf16,
+// operand tiles as 128-byte rows in LDS with XOR-swizzled 16-byte pieces, two LDS stages + two register sets, raw
+// buffer loads whose out-of-range lanes read zeros.  K is the flattened (tap, channel) axis in pieces of 8
+// channels: a K step of 64 may straddle two taps (Cin = 48, 96 ...), every thread resolves its own piece's tap.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_convgemm.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BK = 64;
+constexpr int kTile = BM * BK * 2;               // 16 KiB per operand tile
+
+__device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+// LDS-only barrier (see gemm.hip): does not drain the global loads in flight
+__device__ __forceinline__ void block_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ long xcd_contiguous(long bid, long n) {
+  const long per = (n + 7) >> 3;
+  const long swz = (bid & 7) * per + (bid >> 3);
+  return swz < n ? swz : -1;
+}
+
+// per-dimension tap list, packed by the host: bits [1:0] = count (1..3), then per entry e: bits [2+4e +: 2] = delta + 1,
+// bits [4+4e +: 2] = filter index t
+__device__ __forceinline__ int taps_count(unsigned p) { return p & 3; }
+__device__ __forceinline__ int taps_delta(unsigned p, int e) { return static_cast<int>((p >> (2 + 4 * e)) & 3) - 1; }
+__device__ __forceinline__ int taps_t(unsigned p, int e) { return (p >> (4 + 4 * e)) & 3; }
+
+struct ConvGeom {
+  int N, SD, SH, SW;            // source map
+  int MD, MH, MW;               // row space (per batch element)
+  int OD, OH, OW;               // output map
+  int src_stride, out_stride, opd, oph, opw;
+  int Cin, Cout;                // contraction channels per tap, output channels
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Y = conv(X, Wk) as implicit GEMM.  Block tile 128 rows x (64 TN) output channels, 2 x 2 waves.
+//   split: the K steps are divided among `split` workgroups per tile; with y32 != NULL every workgroup stores its fp32
+//          partial tile to y32[split index][output row][n] (plain 16-byte stores; an empty K range stores zeros) and
+//          transoar_conv3d_finish sums the partials, adds the bias and casts; else (split == 1) bf16 rows go to Y.
+//   classes != 0: data gradient of a stride-2 layer, all eight parity classes of the dx voxels in ONE launch: the
+//          output map (OD, OH, OW) is dx, the source map dy; class (pd, ph, pw) has the rows (OD - pd + 1) / 2 x ...,
+//          1, 2, 4 or 8 taps (per axis, parity 0: tap 1 of dy voxel m; parity 1: taps 0, 2 of dy voxels m + 1, m) and
+//          writes dx voxels 2 m + parity.  Tiles are numbered class by class, the eight-tap class first.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr unsigned kTapsParity0 = 1u | (1u << 2) | (1u << 4);                                   // {(0, 1)}
+constexpr unsigned kTapsParity1 = 2u | (2u << 2) | (0u << 4) | (1u << 6) | (2u << 8);           // {(+1, 0), (0, 2)}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
+    const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wk, const float* __restrict__ bias,
+    unsigned short* __restrict__ Y, float* __restrict__ y32, ConvGeom g, unsigned tp_d, unsigned tp_h, unsigned tp_w,
+    int split, long n_tiles, int tiles_n, int classes, unsigned x_bytes, unsigned w_bytes) {
+  constexpr int BNT = 64 * TN, NB = BNT / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][kTile + BNT * BK * 2];
+  __shared__ int tap_src[27], tap_w[27], tap_e[27];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long tile_id = xcd_contiguous(blockIdx.x, n_tiles * split);
+  if (tile_id < 0) return;
+  const int ks = static_cast<int>(tile_id / n_tiles);              // split index: slowest, so the tiles of one split are adjacent
+  long t = tile_id - static_cast<long>(ks) * n_tiles;
+  if (classes) {
+    // which parity class does tile t belong to?  (wave-uniform; classes in the order 7 .. 0)
+    for (int c = 7; c >= 0; --c) {
+      const int pd = (c >> 2) & 1, ph = (c >> 1) & 1, pw = c & 1;
+      const int md = (g.OD - pd + 1) >> 1, mh = (g.OH - ph + 1) >> 1, mw = (g.OW - pw + 1) >> 1;
+      const long tl = (static_cast<long>(g.N) * md * mh * mw + BM - 1) / BM * tiles_n;
+      if (t < tl || c == 0) {
+        g.MD = md; g.MH = mh; g.MW = mw; g.opd = pd; g.oph = ph; g.opw = pw;
+        tp_d = pd ? kTapsParity1 : kTapsParity0; tp_h = ph ? kTapsParity1 : kTapsParity0; tp_w = pw ? kTapsParity1 : kTapsParity0;
+        break;
+      }
+      t -= tl;
+    }
+    if (g.MD * g.MH * g.MW == 0) return;
+  }
+  const int tm = static_cast<int>(t / tiles_n), tn = static_cast<int>(t % tiles_n);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = tm * BM, n0 = tn * BNT;
+  const int M = g.N * g.MD * g.MH * g.MW;
+  const int nd = taps_count(tp_d), nh = taps_count(tp_h), nw = taps_count(tp_w);
+  const int ntaps = nd * nh * nw;
+  if (tid < ntaps) {
+    const int ed = tid / (nh * nw), r = tid - ed * nh * nw, eh = r / nw, ew = r - eh * nw;
+    tap_src[tid] = ((taps_delta(tp_d, ed) * g.SH + taps_delta(tp_h, eh)) * g.SW + taps_delta(tp_w, ew)) * g.Cin * 2;
+    tap_w[tid] = ((taps_t(tp_d, ed) * 3 + taps_t(tp_h, eh)) * 3 + taps_t(tp_w, ew)) * g.Cout * g.Cin * 2;
+    tap_e[tid] = ed | (eh << 2) | (ew << 4);
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, static_cast<int>(x_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wk), 0, static_cast<int>(w_bytes), 0x00020000);
+
+  // staging: thread -> (row, 16-byte piece): 4 rows of the A tile, NB of the B tile
+  const int s_piece = tid & 7, s_row = tid >> 3;                  // rows s_row + 32 i
+  unsigned a_base[4], b_base[NB];
+  int a_mask[4];                                                  // validity of the row's sources: 3 bits per dimension, by tap-list entry
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + s_row + 32 * i;
+    a_mask[i] = 0;
+    a_base[i] = 0;
+    if (m < M) {
+      const int mw = m % g.MW, r1 = m / g.MW, mh = r1 % g.MH, r2 = r1 / g.MH, md = r2 % g.MD, nb = r2 / g.MD;
+      const int sd = md * g.src_stride, sh = mh * g.src_stride, sw = mw * g.src_stride;
+      a_base[i] = static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) * 2u;
+      int mask = 0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        mask |= (e < nd && static_cast<unsigned>(sd + taps_delta(tp_d, e)) < static_cast<unsigned>(g.SD)) ? (1 << e) : 0;
+        mask |= (e < nh && static_cast<unsigned>(sh + taps_delta(tp_h, e)) < static_cast<unsigned>(g.SH)) ? (8 << e) : 0;
+        mask |= (e < nw && static_cast<unsigned>(sw + taps_delta(tp_w, e)) < static_cast<unsigned>(g.SW)) ? (64 << e) : 0;
+      }
+      a_mask[i] = mask;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int n = n0 + s_row + 32 * i;
+    b_base[i] = n < g.Cout ? static_cast<unsigned>(n) * static_cast<unsigned>(g.Cin) * 2u : 0x80000000u;
+  }
+  __syncthreads();                                                // tap tables
+
+  const int PT = g.Cin >> 3;                                      // 16-byte pieces per tap
+  const int pieces = ntaps * PT;
+  const int KT = (pieces + 7) >> 3;
+  const int kt_per = (KT + split - 1) / split;
+  const int kt0 = ks * kt_per, kt1 = min(KT, kt0 + kt_per);
+  const float inv_pt = 1.0f / static_cast<float>(PT);
+
+  u32x4 ra0[4], rb0[NB], ra1[4], rb1[NB];
+  auto load_tile = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[NB]) {
+    const int j = kt * 8 + s_piece;                               // this thread's piece of the flattened (tap, channel) axis
+    const bool in_k = j < pieces;
+    const int tap = in_k ? static_cast<int>((static_cast<float>(j) + 0.5f) * inv_pt) : 0;
+    const int c8 = j - tap * PT;
+    const int src = tap_src[tap] + c8 * 16, wof = tap_w[tap] + c8 * 16, e = tap_e[tap];
+    const int ed = e & 3, eh = 3 + ((e >> 2) & 3), ew = 6 + (e >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = in_k && ((a_mask[i] >> ed) & (a_mask[i] >> eh) & (a_mask[i] >> ew) & 1);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_base[i] + static_cast<unsigned>(src) : 0x80000000u, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, in_k ? b_base[i] + static_cast<unsigned>(wof) : 0x80000000u, 0, 0);
+  };
+  auto store_tile = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[NB]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = s_row + 32 * i;
+      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ (r & 7)) << 4)]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = s_row + 32 * i;
+      *reinterpret_cast<u32x4*>(&lds[stage][kTile + r * 128 + ((s_piece ^ (r & 7)) << 4)]) = rb[i];
+    }
+  };
+
+  f32x16 acc[TN][2];          // [n tile][m tile] of the wave's part, D = [n][m]
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int fr = lane & 31, kg = lane >> 5;
+  int fa_off[4][2], fb_off[4][TN];
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int piece = 2 * k4 + kg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rm = wm * 64 + i * 32 + fr;
+      fa_off[k4][i] = rm * 128 + ((piece ^ (rm & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int rn = wn * 32 * TN + i * 32 + fr;
+      fb_off[k4][i] = rn * 128 + ((piece ^ (rn & 7)) << 4);
+    }
+  }
+  auto compute = [&](int stage) {
+    const unsigned char* ta = lds[stage];
+    const unsigned char* tb = lds[stage] + kTile;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      s16x8 fa[2], fb[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const s16x8*>(ta + fa_off[k4][i]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const s16x8*>(tb + fb_off[k4][i]);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
+    }
+  };
+  if (kt0 < kt1) {
+    load_tile(kt0, ra0, rb0);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    block_barrier();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
+      compute(0);
+      if (kt + 1 < kt1) store_tile(1, ra1, rb1);
+      block_barrier();
+      if (kt + 1 >= kt1) break;
+      if (kt + 3 < kt1) load_tile(kt + 3, ra1, rb1);
+      compute(1);
+      if (kt + 2 < kt1) store_tile(0, ra0, rb0);
+      block_barrier();
+    }
+  }
+
+  // ---- epilogue
+  const bool direct = g.out_stride == 1 && g.OD == g.MD && g.OH == g.MH && g.OW == g.MW;     // output row = m
+  auto out_row = [&](int m) -> long {
+    if (direct) return m;
+    const int mw = m % g.MW, r1 = m / g.MW, mh = r1 % g.MH, r2 = r1 / g.MH, md = r2 % g.MD, nb = r2 / g.MD;
+    return ((static_cast<long>(nb) * g.OD + md * g.out_stride + g.opd) * g.OH + mh * g.out_stride + g.oph) * g.OW + mw * g.out_stride + g.opw;
+  };
+  if (y32 != nullptr) {
+    // fp32 partial tile of this split: a lane holds 4 consecutive n of its row -> 16-byte stores
+    const long out_rows = static_cast<long>(g.N) * g.OD * g.OH * g.OW;
+    float* part = y32 + static_cast<long>(ks) * out_rows * g.Cout;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = m0 + wm * 64 + b * 32 + fr;
+      if (m >= M) continue;
+      float* dst = part + out_row(m) * g.Cout;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 32 * TN + a * 32 + 8 * q + 4 * kg;
+          if (n < g.Cout)
+            *reinterpret_cast<float4*>(dst + n) = float4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        }
+    }
+    return;
+  }
+  // bf16: the wave's 64 x (32 TN) tile through its own LDS region, rows leave as whole 16-byte pieces (gemm.hip)
+  constexpr int PITCH = 32 * TN * 2 + 16;
+  unsigned char* stage = &lds[0][0] + wave * (64 * PITCH);
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = a * 32 + 8 * q + 4 * kg;
+        const int n = n0 + wn * 32 * TN + nl;
+        float4 bv{0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && n < g.Cout) bv = *reinterpret_cast<const float4*>(bias + n);
+        const float bq4[4] = {bv.x, bv.y, bv.z, bv.w};
+        unsigned short h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = f32_to_bf16(acc[a][b][4 * q + e] + bq4[e]);
+        *reinterpret_cast<uint2*>(stage + (b * 32 + fr) * PITCH + nl * 2) =
+            uint2{static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16), static_cast<unsigned>(h[2]) | (static_cast<unsigned>(h[3]) << 16)};
+      }
+  constexpr int PP = 4 * TN, RP = 64 / PP;                       // 16-byte pieces per row of the wave tile, rows per pass
+  const int piece = lane % PP, r0 = lane / PP;
+#pragma unroll
+  for (int it = 0; it < PP; ++it) {
+    const int row = it * RP + r0;
+    const int m = m0 + wm * 64 + row, n = n0 + wn * 32 * TN + piece * 8;
+    if (m < M && n < g.Cout) {                                     // Cout is a multiple of 8 (checked on the host)
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + piece * 16);
+      *reinterpret_cast<u32x4*>(Y + out_row(m) * g.Cout + n) = v;
+    }
+  }
+}
+
+// y = bf16(sum over the `split` partial maps of y32 + bias): the last pass of a split-K convolution (rows x cout, cout % 8 == 0)
+__global__ __launch_bounds__(256) void conv3d_finish_kernel(const float* __restrict__ y32, const float* __restrict__ bias,
+                                                            unsigned short* __restrict__ y, long n8, int cout, int split) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int c = static_cast<int>((i * 8) % cout);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < split; ++k) {
+    const float4 a = reinterpret_cast<const float4*>(y32)[2 * (k * n8 + i)], b = reinterpret_cast<const float4*>(y32)[2 * (k * n8 + i) + 1];
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bias[c + e];
+  }
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = static_cast<unsigned>(f32_to_bf16(v[2 * e])) | (static_cast<unsigned>(f32_to_bf16(v[2 * e + 1])) << 16);
+  reinterpret_cast<u32x4*>(y)[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// part[chunk][slab(tap)][co][ci] = sum over the voxel rows m of the chunk:  dY[m][co] * X[src(m, tap)][ci]
+// Block tile: (64 TW) co x (64 TW) ci for ONE tap; K = voxels in steps of 32 rows: both tiles are staged K-major
+// ([row][channel], 128 TW-byte rows + 16 bytes of padding) and the MFMA fragments are cut out of them with the
+// transposing ds_read_b64_tr_b16.  grid = voxel chunks x ci tiles x co tiles x taps.  Every block stores its fp32 tile
+// with plain stores into its own chunk's partial map (no atomics); conv3d_wgrad_reduce sums the chunks.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WK = 32;                      // voxel rows per K step
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
+    const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X, float* __restrict__ part, ConvGeom g,
+    unsigned tp_d, unsigned tp_h, unsigned tp_w, int chunks, int rows_per_chunk, int tiles_co, int tiles_ci,
+    unsigned dy_bytes, unsigned x_bytes) {
+  constexpr int BT = 64 * TW;                // block tile side (channels)
+  constexpr int WP = 2 * BT + 16;            // bytes per staged row: BT channels + padding (bank spread for the transposing reads)
+  constexpr int PR = 8 * TW;                 // 16-byte pieces per row
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * WK * WP];       // [stage]: dY tile, then X tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nd = taps_count(tp_d), nh = taps_count(tp_h), nw = taps_count(tp_w);
+  const int ntaps = nd * nh * nw;
+  // block -> (chunk, ci tile, co tile, tap): chunk fastest so that neighbouring blocks read neighbouring voxels
+  long bid = blockIdx.x;
+  const int chunk = static_cast<int>(bid % chunks); bid /= chunks;
+  const int tci = static_cast<int>(bid % tiles_ci); bid /= tiles_ci;
+  const int tco = static_cast<int>(bid % tiles_co); bid /= tiles_co;
+  const int tap = static_cast<int>(bid);
+  if (tap >= ntaps) return;
+  const int ed = tap / (nh * nw), r_ = tap - ed * nh * nw, eh = r_ / nw, ew = r_ - eh * nw;
+  const int dd = taps_delta(tp_d, ed), dh = taps_delta(tp_h, eh), dw = taps_delta(tp_w, ew);
+  const int slab = (taps_t(tp_d, ed) * 3 + taps_t(tp_h, eh)) * 3 + taps_t(tp_w, ew);
+  const int M = g.N * g.MD * g.MH * g.MW;
+  const int m_beg = chunk * rows_per_chunk, m_end = min(M, m_beg + rows_per_chunk);
+  const int co0 = tco * BT, ci0 = tci * BT;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DY), 0, static_cast<int>(dy_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, static_cast<int>(x_bytes), 0x00020000);
+
+  // staging: a K step is 32 rows x PR pieces per operand = 256 TW pieces of 16 bytes: TW per thread and operand
+  const int s_piece = tid % PR, s_row = tid / PR;                 // rows s_row + (32 / TW) i
+  const bool co_ok = co0 + s_piece * 8 < g.Cout, ci_ok = ci0 + s_piece * 8 < g.Cin;
+  const float inv_mw = 1.0f / static_cast<float>(g.MW), inv_mh = 1.0f / static_cast<float>(g.MH), inv_md = 1.0f / static_cast<float>(g.MD);
+  u32x4 ry0[TW], rx0[TW], ry1[TW], rx1[TW];
+  auto load_step = [&](int m_base, u32x4 (&ry)[TW], u32x4 (&rxx)[TW]) {
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      const int m = m_base + s_row + (32 / TW) * i;
+      unsigned yo = 0x80000000u, xo = 0x80000000u;
+      if (m < m_end) {
+        // m -> (nb, md, mh, mw) by float reciprocals: (q + 0.5) / n is >= 0.5 / n away from an integer, more than the
+        // float error for m < 2^21 (checked on the host); an integer division here would cost more than the K step's MFMAs
+        const int r1 = static_cast<int>((static_cast<float>(m) + 0.5f) * inv_mw), mw = m - r1 * g.MW;
+        const int r2 = static_cast<int>((static_cast<float>(r1) + 0.5f) * inv_mh), mh = r1 - r2 * g.MH;
+        const int nb = static_cast<int>((static_cast<float>(r2) + 0.5f) * inv_md), md = r2 - nb * g.MD;
+        const int sd = md * g.src_stride + dd, sh = mh * g.src_stride + dh, sw = mw * g.src_stride + dw;
+        if (co_ok) yo = (static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) + co0 + s_piece * 8) * 2u;
+        if (ci_ok && static_cast<unsigned>(sd) < static_cast<unsigned>(g.SD) && static_cast<unsigned>(sh) < static_cast<unsigned>(g.SH) &&
+            static_cast<unsigned>(sw) < static_cast<unsigned>(g.SW))
+          xo = (static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) + ci0 + s_piece * 8) * 2u;
+      }
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, yo, 0, 0);
+      rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0);
+    }
+  };
+  auto store_step = [&](int stage, const u32x4 (&ry)[TW], const u32x4 (&rxx)[TW]) {
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      const int r = s_row + (32 / TW) * i;
+      *reinterpret_cast<u32x4*>(&lds[stage][r * WP + s_piece * 16]) = ry[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][WK * WP + r * WP + s_piece * 16]) = rxx[i];
+    }
+  };
+  f32x16 acc[TW][TW];          // [co tile][ci tile] of the wave's quadrant
+#pragma unroll
+  for (int a = 0; a < TW; ++a)
+#pragma unroll
+    for (int b = 0; b < TW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  // transposing fragment read (msda3d_mma.hpp): within 16 lanes, lane supplies row (lane & 15) >> 2 of a 4-row set and
+  // 4 channels; receives its channel's 4 rows.  Rows 8 kg + {0..3} and + 4 make the 8 K values of the lane's fragment.
+  const int kg = lane >> 5;
+  const int t_row = 8 * kg + ((lane & 15) >> 2), t_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto frag = [&](const unsigned char* tile, int k16, int ch0) -> s16x8 {
+    const unsigned char* p = tile + (k16 * 16 + t_row) * WP + (ch0 + t_ch) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WP));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto compute = [&](int stage) {
+    const unsigned char* ty = lds[stage];
+    const unsigned char* tx = lds[stage] + WK * WP;
+#pragma unroll
+    for (int k16 = 0; k16 < WK / 16; ++k16) {
+      s16x8 fy[TW], fx[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        fy[i] = frag(ty, k16, wm * 32 * TW + i * 32);
+        fx[i] = frag(tx, k16, wn * 32 * TW + i * 32);
+      }
+#pragma unroll
+      for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b) acc[a][b] = mfma(fy[a], fx[b], acc[a][b]);      // D[co][ci] += dY[k][co] X[k][ci]
+    }
+  };
+  const int steps = (m_end - m_beg + WK - 1) / WK;
+  if (steps > 0) {
+    load_step(m_beg, ry0, rx0);
+    if (steps > 1) load_step(m_beg + WK, ry1, rx1);
+    store_step(0, ry0, rx0);
+    block_barrier();
+    for (int s = 0; s < steps; s += 2) {
+      if (s + 2 < steps) load_step(m_beg + (s + 2) * WK, ry0, rx0);
+      compute(0);
+      if (s + 1 < steps) store_step(1, ry1, rx1);
+      block_barrier();
+      if (s + 1 >= steps) break;
+      if (s + 3 < steps) load_step(m_beg + (s + 3) * WK, ry1, rx1);
+      compute(1);
+      if (s + 2 < steps) store_step(0, ry0, rx0);
+      block_barrier();
+    }
+  }
+  // D layout: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 kg (co), column lane & 31 (ci): 128-byte rows
+  float* dst = part + (static_cast<long>(chunk) * 27 + slab) * g.Cout * g.Cin;
+#pragma unroll
+  for (int a = 0; a < TW; ++a)
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+      const int ci = ci0 + wn * 32 * TW + b * 32 + (lane & 31);
+      if (ci >= g.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 * TW + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (co < g.Cout) dst[static_cast<long>(co) * g.Cin + ci] = acc[a][b][r];
+      }
+    }
+}
+
+// dw[co][ci][tap] (taps_out == 27: nn.Conv3d's weight layout) or dw[co][ci] (taps_out == 1: slab `slab0` only) =
+// sum over the chunks of part[chunk][slab][co][ci]
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int chunks,
+                                                                  int taps_out, int slab0, long coci) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;          // over taps_out * co * ci, ci fastest
+  if (i >= taps_out * coci) return;
+  const int tap = static_cast<int>(i / coci);
+  const long e = i - tap * coci;
+  const int slab = taps_out == 1 ? slab0 : tap;
+  float v = 0.f;
+  for (int k = 0; k < chunks; ++k) v += part[(static_cast<long>(k) * 27 + slab) * coci + e];
+  if (taps_out == 1) dw[e] = v;
+  else dw[e * 27 + tap] = v;
+}
+
+int check_geom(const ConvGeom& g) {
+  if (g.N <= 0 || g.SD <= 0 || g.SH <= 0 || g.SW <= 0 || g.MD <= 0 || g.MH <= 0 || g.MW <= 0 || g.OD <= 0 || g.OH <= 0 || g.OW <= 0 ||
+      g.Cin <= 0 || g.Cout <= 0 || (g.Cin & 7) || (g.Cout & 7) || g.src_stride < 1 || g.src_stride > 2 || g.out_stride < 1 || g.out_stride > 2)
+    return TRANSOAR_CONVGEMM_ERR_DIM;
+  const long src = static_cast<long>(g.N) * g.SD * g.SH * g.SW * g.Cin * 2, out = static_cast<long>(g.N) * g.OD * g.OH * g.OW * g.Cout * 2;
+  const long rows = static_cast<long>(g.N) * g.MD * g.MH * g.MW;
+  if (src >= 0x7ffffff0L || out >= 0x7ffffff0L * 2 || rows >= (1L << 31) || rows * g.Cout * 2 >= 0x7ffffff0L * 2 || 27L * g.Cout * g.Cin * 2 >= 0x7ffffff0L)
+    return TRANSOAR_CONVGEMM_ERR_DIM;
+  return 0;
+}
+bool taps_ok(unsigned p) { return (p & 3) >= 1 && (p & 3) <= 3; }
+
+}  // namespace
+
+extern "C" int transoar_conv3d_igemm(const void* x, const void* wk, const float* bias, void* y, float* y32, int N, int SD,
+                                     int SH, int SW, int Cin, int Cout, int MD, int MH, int MW, int src_stride, int OD, int OH,
+                                     int OW, int out_stride, int opd, int oph, int opw, unsigned taps_d, unsigned taps_h,
+                                     unsigned taps_w, int split, int classes, void* hip_stream) {
+  if (!x || !wk || (!y && !y32)) return TRANSOAR_CONVGEMM_ERR_NULL;
+  if (classes) {               // all parity classes of a stride-2 data gradient: the row space is derived per class
+    MD = (OD + 1) / 2; MH = (OH + 1) / 2; MW = (OW + 1) / 2;
+    src_stride = 1; out_stride = 2; opd = oph = opw = 0;
+    taps_d = taps_h = taps_w = kTapsParity1;
+  }
+  const ConvGeom g{N, SD, SH, SW, MD, MH, MW, OD, OH, OW, src_stride, out_stride, opd, oph, opw, Cin, Cout};
+  const int rc = check_geom(g);
+  if (rc) return rc;
+  if (!taps_ok(taps_d) || !taps_ok(taps_h) || !taps_ok(taps_w) || split < 1 || (split > 1 && !y32)) return TRANSOAR_CONVGEMM_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const bool narrow = Cout <= 64;                       // 128 x 64 tiles: up to 64 output channels do not half-fill a 128-wide one
+  const int bn = narrow ? 64 : 128;
+  const int tiles_n = (Cout + bn - 1) / bn;
+  long n_tiles = 0;
+  if (classes) {
+    for (int c = 0; c < 8; ++c) {
+      const long md = (OD - ((c >> 2) & 1) + 1) / 2, mh = (OH - ((c >> 1) & 1) + 1) / 2, mw = (OW - (c & 1) + 1) / 2;
+      n_tiles += (N * md * mh * mw + BM - 1) / BM * tiles_n;
+    }
+  } else {
+    n_tiles = (static_cast<long>(N) * MD * MH * MW + BM - 1) / BM * tiles_n;
+  }
+  const long blocks = ((n_tiles * split + 7) / 8) * 8;
+  const unsigned xb = static_cast<unsigned>(static_cast<long>(N) * SD * SH * SW * Cin * 2), wb = static_cast<unsigned>(27L * Cout * Cin * 2);
+  if (narrow)
+    hipLaunchKernelGGL(conv3d_igemm_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(x),
+                       static_cast<const unsigned short*>(wk), bias, static_cast<unsigned short*>(y), y32, g, taps_d, taps_h, taps_w,
+                       split, n_tiles, tiles_n, classes, xb, wb);
+  else
+    hipLaunchKernelGGL(conv3d_igemm_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(x),
+                       static_cast<const unsigned short*>(wk), bias, static_cast<unsigned short*>(y), y32, g, taps_d, taps_h, taps_w,
+                       split, n_tiles, tiles_n, classes, xb, wb);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_finish(const float* y32, const float* bias, void* y, long rows, int cout, int split, void* hip_stream) {
+  if (!y32 || !y) return TRANSOAR_CONVGEMM_ERR_NULL;
+  if (rows <= 0 || cout <= 0 || (cout & 7) || split < 1) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const long n8 = rows * cout / 8;
+  hipLaunchKernelGGL(conv3d_finish_kernel, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     y32, bias, static_cast<unsigned short*>(y), n8, cout, split);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks) { return 27L * Cin * Cout * chunks; }
+
+extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
+                                     int Cout, int MD, int MH, int MW, int src_stride, unsigned taps_d, unsigned taps_h,
+                                     unsigned taps_w, int chunks, int taps_out, void* hip_stream) {
+  if (!dy || !x || !part || !dw) return TRANSOAR_CONVGEMM_ERR_NULL;
+  const ConvGeom g{N, SD, SH, SW, MD, MH, MW, MD, MH, MW, src_stride, 1, 0, 0, 0, Cin, Cout};
+  const int rc = check_geom(g);
+  if (rc) return rc;
+  if (!taps_ok(taps_d) || !taps_ok(taps_h) || !taps_ok(taps_w) || chunks < 1 || (taps_out != 1 && taps_out != 27)) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const long M = static_cast<long>(N) * MD * MH * MW;
+  if (M >= (1L << 21)) return TRANSOAR_CONVGEMM_ERR_DIM;          // row decomposition by float reciprocals (conv3d_wgrad_kernel)
+  const int max_chunks = chunks;
+  if (chunks > M) chunks = static_cast<int>(M);
+  const int rows_per_chunk = static_cast<int>(((M + chunks - 1) / chunks + WK - 1) / WK * WK);
+  chunks = static_cast<int>((M + rows_per_chunk - 1) / rows_per_chunk);
+  if (chunks > max_chunks) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const int ntaps = static_cast<int>((taps_d & 3) * (taps_h & 3) * (taps_w & 3));
+  if (taps_out == 1 && ntaps != 1) return TRANSOAR_CONVGEMM_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const bool small = Cin <= 64 && Cout <= 64;              // 64 x 64 tiles for the 24..64-channel layers
+  const int bt = small ? 64 : 128;
+  const int tiles_co = (Cout + bt - 1) / bt, tiles_ci = (Cin + bt - 1) / bt;
+  const long blocks = static_cast<long>(chunks) * tiles_ci * tiles_co * ntaps;
+  if (blocks >= (1L << 31)) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const unsigned dyb = static_cast<unsigned>(M * Cout * 2), xb = static_cast<unsigned>(static_cast<long>(N) * SD * SH * SW * Cin * 2);
+  if (small)
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, dyb, xb);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, dyb, xb);
+  const long coci = static_cast<long>(Cout) * Cin;
+  int slab0 = 13;
+  if (taps_out == 1) slab0 = static_cast<int>((((taps_d >> 4) & 3) * 3 + ((taps_h >> 4) & 3)) * 3 + ((taps_w >> 4) & 3));
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((taps_out * coci + 255) / 256)), dim3(256), 0, st, part, dw, chunks,
+                     taps_out, slab0, coci);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_convgemm_abi_version(void) { return 1; }

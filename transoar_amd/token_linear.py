@@ -23,7 +23,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import gemm, rows
+from . import conv_gemm, gemm, rows
 
 MIN_TOKENS = 32768          # below this the stock path is as fast
 LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
@@ -46,10 +46,18 @@ def _chunks(tokens, n_out, n_in):
     return tokens // size, size
 
 
+# the hand-written voxel-major ("TN") GEMM of csrc/conv_gemm.hip (its one-tap case): TRANSOAR_HIP_WGRAD=0 goes back to
+# the chunked hipBLASLt batch
+USE_HIP_WGRAD = os.environ.get("TRANSOAR_HIP_WGRAD", "1") == "1"
+
+
 def weight_grad(gy, x):
-    """(T, N)^T @ (T, K) -> (N, K) fp32, token axis in batched chunks."""
+    """(T, N)^T @ (T, K) -> (N, K) fp32: the token axis is the contraction."""
     t, n = gy.shape
     k = x.shape[1]
+    if (USE_HIP_WGRAD and gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.is_contiguous()
+            and x.is_contiguous() and n % 8 == 0 and k % 8 == 0 and t < (1 << 21)):
+        return conv_gemm.linear_wgrad(x, gy)
     b, size = _chunks(t, n, k)
     main = b * size
     out = torch.bmm(gy[:main].view(b, size, n).transpose(1, 2), x[:main].view(b, size, k),
