@@ -38,13 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The torch-side convolutions (everything that is not yet a hand-written kernel) go
-# through MIOpen, whose untuned fallback for these 3-D bf16 shapes is a naive
-# reference kernel (1.5 s per step for one layer).  miopen_db/ holds the user
-# find-db tuned once on an MI355X (python bench.py --miopen-benchmark with
-# MIOPEN_USER_DB_PATH pointing there); using it is plumbing, not product.
-_DB = os.path.join(ROOT, "miopen_db")
-if os.path.isdir(_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
+# Round 3: no convolution of the default model goes through MIOpen any more (csrc/conv3d.hip, csrc/conv_gemm.hip), so
+# the bench no longer points MIOpen at a tuned find-db.  The one left is the k = s = 2 patch-merging convolution of the
+# Swin encoder (BASELINE config #4, --swin): for that run only, tools/miopen_db/ (tuned once on an MI355X) is used.
+_DB = os.path.join(ROOT, "tools", "miopen_db")
+if "--swin" in sys.argv and os.path.isdir(_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
     os.environ["MIOPEN_USER_DB_PATH"] = _DB
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -63,7 +61,7 @@ def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
 
 
 BWD_KINDS = ("bwd_query", "cell_count", "scan", "cell_fill", "pull", "value_tile", "value_cells", "bwd_generic")
-PMC_FILE = "r02_msda_pmc.json"
+PMC_FILE = "r03_msda_pmc.json"
 
 
 def pmc_traffic(kind, dims):
@@ -80,7 +78,7 @@ def pmc_traffic(kind, dims):
         if kind == "bwd":       # the whole chain
             names = [k for k in pmc["kernels"] if k.startswith("bwd_") or k.startswith("cell_fill") or k in ("scan_tiles", "coarse_rows_store")]
             return round(sum(pmc["kernels"][k].get("hbm_bytes_per_launch", 0.0) for k in names) / 1e6, 1)
-        return round(pmc["kernels"]["fwd_mma"]["hbm_bytes_per_launch"] / 1e6, 1)
+        return round(pmc["kernels"]["fwd_pcm"]["hbm_bytes_per_launch"] / 1e6, 1)
     except Exception:
         return None
 
@@ -134,7 +132,7 @@ def cpu_step_leg():
     restatement of ms_deform_attn_core_pytorch injected, fp32, batch 1 at the flagship geometry, refine on,
     every host core; 1 warm + 3 timed iterations, median; forward-only and the full training step.  Minutes per
     iteration: run separately (python bench.py --cpu-baseline-only --cpu-baseline-step), the result is kept in
-    profiles/r02_cpu_step.json and quoted by the default run as `cpu_step`."""
+    profiles/r03_cpu_step.json and quoted by the default run as `cpu_step`."""
     import torch
     from oracle.torch_ref import msda3d_core_torch
     from transoar_amd import ms_deform_attn
@@ -180,11 +178,11 @@ def cpu_step_leg():
 
 
 def cpu_step_record():
-    """The committed whole-step CPU measurement (profiles/r02_cpu_step.json), quoted with its provenance."""
+    """The committed whole-step CPU measurement (profiles/r03_cpu_step.json), quoted with its provenance."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_step.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_step.json")))
         rec["provenance"] = "measured separately on an MI355X box's host by `bench.py --cpu-baseline-only --cpu-baseline-step`, " \
-                            "profiles/r02_cpu_step.json; NOT re-measured in this run (minutes per iteration)"
+                            "profiles/r03_cpu_step.json; NOT re-measured in this run (minutes per iteration)"
         return rec
     except Exception:
         return None
@@ -210,7 +208,7 @@ def main():
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="with --cpu-baseline-only: time the WHOLE use_cuda=False training step of the model on all host "
                          "cores (1 warm + 3 timed, forward-only and full step; minutes per step) instead of the bounded "
-                         "operator sample; writes profiles/r02_cpu_step.json")
+                         "operator sample; writes profiles/r03_cpu_step.json")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=300.0)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -358,9 +356,9 @@ def main():
         if "fwd" in kernels:                    # the MSDeformAttn forward gather: the kernel north_star names
             b = msda_algorithmic_bytes("fwd", **dims)
             gbps = b / kernels["fwd"]["avg_ms"] / 1e6
-            roofline = {"kernel": "msda3d_fwd_mma", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+            roofline = {"kernel": "msda3d_fwd_pcm", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("fwd", dims),
-                        "traffic_unit": "MB per launch (PMC, profiles/%s)" % PMC_FILE,
+                        "traffic_unit": "MB per launch (PMC, profiles/%s: collected on the op bench's jittered locations, not on the step's launches)" % PMC_FILE,
                         "avg_launch_ms": kernels["fwd"]["avg_ms"], "algorithmic_MB": round(b / 1e6, 1), "timing": timing}
         chain = [k for k in BWD_KINDS if k in kernels]
         if chain:                               # one backward call = the chain of these kernels, against B_bwd

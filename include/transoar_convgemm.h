@@ -59,10 +59,10 @@ int transoar_conv3d_finish(const float* y32, const float* bias, void* y, long ro
  * tap of the lists, nn.Linear's (out, in)) = sum_m dy[m][co] * x[src(m, tap)][ci]          (fp32, written completely)
  *   rows m over (N, MD, MH, MW) = the voxels of dy (Cout channels); x is the source map (N, SD, SH, SW, Cin).
  *   chunks: number of voxel ranges the rows are split into (parallelism over the contraction axis); `part` is a
- *   scratch buffer of transoar_conv3d_wgrad_part_floats(Cin, Cout, chunks) floats holding one partial map per
+ *   scratch buffer of transoar_conv3d_wgrad_part_floats(Cin, Cout, chunks, taps_out) floats holding one partial map per
  *   chunk (no atomics); a second kernel sums them into dw.
  */
-long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks);
+long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks, int taps_out);
 int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
                           int Cout, int MD, int MH, int MW, int src_stride,
                           unsigned taps_d, unsigned taps_h, unsigned taps_w, int chunks, int taps_out, void* hip_stream);

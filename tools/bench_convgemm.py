@@ -4,7 +4,7 @@ find-db, NDHWC operands) on the backbone's real shapes, batch 2, bf16: forward, 
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_db"))
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "tools", "miopen_db"))
 import torch
 import torch.nn.functional as F
 from transoar_amd import conv_gemm as G

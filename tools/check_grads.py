@@ -2,7 +2,7 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_db"))
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "tools", "miopen_db"))
 from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
 from transoar_amd.matcher import DenseTargets
 from transoar_amd.train_step import TrainStep

@@ -3,7 +3,7 @@ torch.cat calls that return new memory, by source line and bytes (debug aid, not
 import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "miopen_db"))
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "tools", "miopen_db"))
 import torch
 from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
 from transoar_amd.matcher import DenseTargets

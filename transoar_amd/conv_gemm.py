@@ -28,7 +28,7 @@ def _load():
     lib.transoar_conv3d_wgrad.restype = i
     lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
     lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
-    lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i]
+    lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i, i]
     lib.transoar_convgemm_abi_version.restype = i
     if lib.transoar_convgemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -53,7 +53,7 @@ TAPS_ONE = _taps([(0, 1)])
 
 # launches with fewer output tiles than this split their K steps (fp32 atomics + a cast pass)
 SPLIT_BELOW_TILES = 384
-WGRAD_BLOCKS = 2048
+WGRAD_BLOCKS = 1024
 
 
 def _check(rc, what):
@@ -144,8 +144,8 @@ def _wgrad(x2, gy2, geom, taps, taps_out, out_shape):
     bt = 64 if (ci <= 64 and co <= 64) else 128
     tiles = nt * ((co + bt - 1) // bt) * ((ci + bt - 1) // bt)
     rows = n * md * mh * mw
-    chunks = max(1, min(WGRAD_BLOCKS // tiles, rows // 256 if rows >= 256 else 1))
-    part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks), dtype=torch.float32, device=x2.device)
+    chunks = max(1, min(WGRAD_BLOCKS // tiles, rows // 1024 if rows >= 1024 else 1))      # >= 16 K steps of 64 rows per block
+    part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks, taps_out), dtype=torch.float32, device=x2.device)
     dw = torch.empty(out_shape, dtype=torch.float32, device=x2.device)
     with torch.cuda.device(x2.device):
         _check(lib.transoar_conv3d_wgrad(gy2.data_ptr(), x2.data_ptr(), part.data_ptr(), dw.data_ptr(), n, sd, sh, sw, ci, co, md, mh, mw,

@@ -128,6 +128,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, static_cast<int>(x_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wk), 0, static_cast<int>(w_bytes), 0x00020000);
 
+  // m -> (nb, md, mh, mw) by float reciprocals: (q + 0.5) / n is >= 0.5 / n away from an integer, more than the float error
+  // for m < 2^21 (checked on the host).  Integer divisions here cost as much as the K loop of a one-tap tile.
+  const float inv_mw = 1.0f / static_cast<float>(g.MW), inv_mh = 1.0f / static_cast<float>(g.MH), inv_md = 1.0f / static_cast<float>(g.MD);
+  auto split_row = [&](int m, int& nb, int& md, int& mh, int& mw) {
+    const int r1 = static_cast<int>((static_cast<float>(m) + 0.5f) * inv_mw);
+    mw = m - r1 * g.MW;
+    const int r2 = static_cast<int>((static_cast<float>(r1) + 0.5f) * inv_mh);
+    mh = r1 - r2 * g.MH;
+    nb = static_cast<int>((static_cast<float>(r2) + 0.5f) * inv_md);
+    md = r2 - nb * g.MD;
+  };
   // staging: thread -> (row, 16-byte piece): 4 rows of the A tile, NB of the B tile
   const int s_piece = tid & 7, s_row = tid >> 3;                  // rows s_row + 32 i
   unsigned a_base[4], b_base[NB];
@@ -138,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
     a_mask[i] = 0;
     a_base[i] = 0;
     if (m < M) {
-      const int mw = m % g.MW, r1 = m / g.MW, mh = r1 % g.MH, r2 = r1 / g.MH, md = r2 % g.MD, nb = r2 / g.MD;
+      int nb, md, mh, mw;
+      split_row(m, nb, md, mh, mw);
       const int sd = md * g.src_stride, sh = mh * g.src_stride, sw = mw * g.src_stride;
       a_base[i] = static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) * 2u;
       int mask = 0;
@@ -256,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   const bool direct = g.out_stride == 1 && g.OD == g.MD && g.OH == g.MH && g.OW == g.MW;     // output row = m
   auto out_row = [&](int m) -> long {
     if (direct) return m;
-    const int mw = m % g.MW, r1 = m / g.MW, mh = r1 % g.MH, r2 = r1 / g.MH, md = r2 % g.MD, nb = r2 / g.MD;
+    int nb, md, mh, mw;
+    split_row(m, nb, md, mh, mw);
     return ((static_cast<long>(nb) * g.OD + md * g.out_stride + g.opd) * g.OH + mh * g.out_stride + g.oph) * g.OW + mw * g.out_stride + g.opw;
   };
   if (y32 != nullptr) {
@@ -340,12 +353,12 @@ __global__ __launch_bounds__(256) void conv3d_finish_kernel(const float* __restr
 // transposing ds_read_b64_tr_b16.  grid = voxel chunks x ci tiles x co tiles x taps.  Every block stores its fp32 tile
 // with plain stores into its own chunk's partial map (no atomics); conv3d_wgrad_reduce sums the chunks.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int WK = 32;                      // voxel rows per K step
+constexpr int WK = 64;                      // voxel rows per K step
 
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X, float* __restrict__ part, ConvGeom g,
-    unsigned tp_d, unsigned tp_h, unsigned tp_w, int chunks, int rows_per_chunk, int tiles_co, int tiles_ci,
+    unsigned tp_d, unsigned tp_h, unsigned tp_w, int chunks, int rows_per_chunk, int tiles_co, int tiles_ci, int slabs,
     unsigned dy_bytes, unsigned x_bytes) {
   constexpr int BT = 64 * TW;                // block tile side (channels)
   constexpr int WP = 2 * BT + 16;            // bytes per staged row: BT channels + padding (bank spread for the transposing reads)
@@ -371,15 +384,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DY), 0, static_cast<int>(dy_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, static_cast<int>(x_bytes), 0x00020000);
 
-  // staging: a K step is 32 rows x PR pieces per operand = 256 TW pieces of 16 bytes: TW per thread and operand
-  const int s_piece = tid % PR, s_row = tid / PR;                 // rows s_row + (32 / TW) i
+  // staging: a K step is WK rows x PR pieces per operand = 8 WK TW pieces of 16 bytes: NS per thread and operand
+  constexpr int NS = WK * PR / 256, RS = 256 / PR;                // pieces per thread, rows per pass
+  const int s_piece = tid % PR, s_row = tid / PR;                 // rows s_row + RS i
   const bool co_ok = co0 + s_piece * 8 < g.Cout, ci_ok = ci0 + s_piece * 8 < g.Cin;
   const float inv_mw = 1.0f / static_cast<float>(g.MW), inv_mh = 1.0f / static_cast<float>(g.MH), inv_md = 1.0f / static_cast<float>(g.MD);
-  u32x4 ry0[TW], rx0[TW], ry1[TW], rx1[TW];
-  auto load_step = [&](int m_base, u32x4 (&ry)[TW], u32x4 (&rxx)[TW]) {
+  u32x4 ry0[NS], rx0[NS], ry1[NS], rx1[NS];
+  auto load_step = [&](int m_base, u32x4 (&ry)[NS], u32x4 (&rxx)[NS]) {
 #pragma unroll
-    for (int i = 0; i < TW; ++i) {
-      const int m = m_base + s_row + (32 / TW) * i;
+    for (int i = 0; i < NS; ++i) {
+      const int m = m_base + s_row + RS * i;
       unsigned yo = 0x80000000u, xo = 0x80000000u;
       if (m < m_end) {
         // m -> (nb, md, mh, mw) by float reciprocals: (q + 0.5) / n is >= 0.5 / n away from an integer, more than the
@@ -397,10 +411,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
       rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0);
     }
   };
-  auto store_step = [&](int stage, const u32x4 (&ry)[TW], const u32x4 (&rxx)[TW]) {
+  auto store_step = [&](int stage, const u32x4 (&ry)[NS], const u32x4 (&rxx)[NS]) {
 #pragma unroll
-    for (int i = 0; i < TW; ++i) {
-      const int r = s_row + (32 / TW) * i;
+    for (int i = 0; i < NS; ++i) {
+      const int r = s_row + RS * i;
       *reinterpret_cast<u32x4*>(&lds[stage][r * WP + s_piece * 16]) = ry[i];
       *reinterpret_cast<u32x4*>(&lds[stage][WK * WP + r * WP + s_piece * 16]) = rxx[i];
     }
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     }
   }
   // D layout: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 kg (co), column lane & 31 (ci): 128-byte rows
-  float* dst = part + (static_cast<long>(chunk) * 27 + slab) * g.Cout * g.Cin;
+  float* dst = part + (static_cast<long>(chunk) * slabs + (slabs == 1 ? 0 : slab)) * g.Cout * g.Cin;      // slabs == 1: the one tap of a projection
 #pragma unroll
   for (int a = 0; a < TW; ++a)
 #pragma unroll
@@ -474,19 +488,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     }
 }
 
-// dw[co][ci][tap] (taps_out == 27: nn.Conv3d's weight layout) or dw[co][ci] (taps_out == 1: slab `slab0` only) =
-// sum over the chunks of part[chunk][slab][co][ci]
+// dw[co][ci][tap] (slabs == 27: nn.Conv3d's weight layout) or dw[co][ci] (slabs == 1) = sum over the chunks of
+// part[chunk][slab][co][ci].  A block takes 32 consecutive (co, ci) pairs x all slabs: the partial maps are read along ci
+// (128-byte segments), the 32 x 27 results are turned through LDS and leave as one contiguous run.
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int chunks,
-                                                                  int taps_out, int slab0, long coci) {
-  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;          // over taps_out * co * ci, ci fastest
-  if (i >= taps_out * coci) return;
-  const int tap = static_cast<int>(i / coci);
-  const long e = i - tap * coci;
-  const int slab = taps_out == 1 ? slab0 : tap;
-  float v = 0.f;
-  for (int k = 0; k < chunks; ++k) v += part[(static_cast<long>(k) * 27 + slab) * coci + e];
-  if (taps_out == 1) dw[e] = v;
-  else dw[e * 27 + tap] = v;
+                                                                  int slabs, long coci) {
+  __shared__ float sh[32 * 27];
+  const long e0 = static_cast<long>(blockIdx.x) * 32;
+  const int n = 32 * slabs;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    const int tap = idx >> 5, el = idx & 31;
+    float v = 0.f;
+    if (e0 + el < coci)
+      for (int k = 0; k < chunks; ++k) v += part[(static_cast<long>(k) * slabs + tap) * coci + e0 + el];
+    sh[el * slabs + tap] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n; idx += 256)
+    if (e0 * slabs + idx < coci * slabs) dw[e0 * slabs + idx] = sh[idx];
 }
 
 int check_geom(const ConvGeom& g) {
@@ -517,6 +536,7 @@ extern "C" int transoar_conv3d_igemm(const void* x, const void* wk, const float*
   const int rc = check_geom(g);
   if (rc) return rc;
   if (!taps_ok(taps_d) || !taps_ok(taps_h) || !taps_ok(taps_w) || split < 1 || (split > 1 && !y32)) return TRANSOAR_CONVGEMM_ERR_DIM;
+  if (static_cast<long>(N) * MD * MH * MW >= (1L << 21)) return TRANSOAR_CONVGEMM_ERR_DIM;       // row decomposition by float reciprocals
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const bool narrow = Cout <= 64;                       // 128 x 64 tiles: up to 64 output channels do not half-fill a 128-wide one
   const int bn = narrow ? 64 : 128;
@@ -552,7 +572,7 @@ extern "C" int transoar_conv3d_finish(const float* y32, const float* bias, void*
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks) { return 27L * Cin * Cout * chunks; }
+extern "C" long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks, int taps_out) { return static_cast<long>(taps_out) * Cin * Cout * chunks; }
 
 extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
                                      int Cout, int MD, int MH, int MW, int src_stride, unsigned taps_d, unsigned taps_h,
@@ -580,15 +600,12 @@ extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part,
   const unsigned dyb = static_cast<unsigned>(M * Cout * 2), xb = static_cast<unsigned>(static_cast<long>(N) * SD * SH * SW * Cin * 2);
   if (small)
     hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
-                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, dyb, xb);
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb);
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
-                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, dyb, xb);
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb);
   const long coci = static_cast<long>(Cout) * Cin;
-  int slab0 = 13;
-  if (taps_out == 1) slab0 = static_cast<int>((((taps_d >> 4) & 3) * 3 + ((taps_h >> 4) & 3)) * 3 + ((taps_w >> 4) & 3));
-  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((taps_out * coci + 255) / 256)), dim3(256), 0, st, part, dw, chunks,
-                     taps_out, slab0, coci);
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((coci + 31) / 32)), dim3(256), 0, st, part, dw, chunks, taps_out, coci);
   return static_cast<int>(hipGetLastError());
 }
 

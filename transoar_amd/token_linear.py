@@ -46,9 +46,11 @@ def _chunks(tokens, n_out, n_in):
     return tokens // size, size
 
 
-# the hand-written voxel-major ("TN") GEMM of csrc/conv_gemm.hip (its one-tap case): TRANSOAR_HIP_WGRAD=0 goes back to
-# the chunked hipBLASLt batch
-USE_HIP_WGRAD = os.environ.get("TRANSOAR_HIP_WGRAD", "1") == "1"
+# TRANSOAR_HIP_WGRAD=1: the hand-written voxel-major ("TN") GEMM of csrc/conv_gemm.hip (its one-tap case) instead of the
+# chunked hipBLASLt batch.  Measured at the 234 000-token shapes (tools/bench_gemm.py, profiles/r03_gemm_bench.jsonl):
+# 0.28 / 0.49 / 0.46 ms against 0.14 / 0.29 / 0.27 ms -- the batch stays the default for the projections; the
+# convolutions' weight gradients (27 taps, shifted operand) have no library counterpart and run on the kernel.
+USE_HIP_WGRAD = os.environ.get("TRANSOAR_HIP_WGRAD", "0") == "1"
 
 
 def weight_grad(gy, x):
