@@ -126,3 +126,34 @@ def test_sampling_head_and_colsum_argument_errors():
     assert c(None, p16, p16, 8, 8, None) == -1
     assert c(p16, p16, p16, 8, 12, None) == -2                             # cols not a multiple of 8
     assert rows.transoar_rows_colsum_workspace_floats(384) == 1024 * 384
+
+
+def test_convgemm_and_fused_gather_argument_errors():
+    """The round-3 entry points validate on the host too: the implicit-GEMM convolutions (include/transoar_convgemm.h) and
+    the fused head + gather (transoar_msda3d_forward_fused)."""
+    cg = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_convgemm.so"))
+    buf = (ctypes.c_char * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    p, i, u = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint
+    f = cg.transoar_conv3d_igemm
+    f.argtypes = [p] * 5 + [i] * 17 + [u] * 3 + [i, i, p]
+    taps = 3 | (0 << 2) | (0 << 4) | (1 << 6) | (1 << 8) | (2 << 10) | (2 << 12)         # (-1,0) (0,1) (+1,2)
+    geom = (1, 4, 4, 8, 16, 16, 4, 4, 8, 1, 4, 4, 8, 1, 0, 0, 0)
+    assert f(None, p16, None, p16, None, *geom, taps, taps, taps, 1, 0, None) == -1
+    assert f(p16, p16, None, p16, None, 1, 4, 4, 8, 12, 16, 4, 4, 8, 1, 4, 4, 8, 1, 0, 0, 0, taps, taps, taps, 1, 0, None) == -2    # Cin % 8
+    assert f(p16, p16, None, p16, None, *geom, 0, taps, taps, 1, 0, None) == -2           # empty tap list
+    assert f(p16, p16, None, p16, None, *geom, taps, taps, taps, 2, 0, None) == -2        # split > 1 needs the partial maps
+    w = cg.transoar_conv3d_wgrad
+    w.argtypes = [p] * 4 + [i] * 10 + [u] * 3 + [i, i, p]
+    assert w(p16, p16, None, p16, 1, 4, 4, 8, 16, 16, 4, 4, 8, 1, taps, taps, taps, 4, 27, None) == -1
+    assert w(p16, p16, p16, p16, 1, 4, 4, 8, 16, 16, 4, 4, 8, 1, taps, taps, taps, 4, 5, None) == -2       # taps_out is 1 or 27
+    cg.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
+    assert cg.transoar_conv3d_wgrad_part_floats(96, 96, 10, 27) == 27 * 96 * 96 * 10
+
+    from transoar_amd import _native
+    shapes = (ctypes.c_int64 * 3)(2, 2, 2)
+    g = _native.lib.transoar_msda3d_forward_fused
+    assert g(None, p16, p16, 8, p16, 1, 8, 6, 64, 1, 4, 2, ctypes.addressof(shapes), None) == -1
+    assert g(p16, p16, p16, 8, p16, 1, 8, 6, 64, 1, 4, 0, ctypes.addressof(shapes), None) == -3      # fp32 value: 16-bit storage only
+    assert g(p16, p16, p16, 8, p16, 1, 8, 6, 32, 1, 4, 2, ctypes.addressof(shapes), None) == -2      # 32 channels per head: not this kernel's form
+    assert g(p16, p16, p16, 5, p16, 1, 8, 6, 64, 1, 4, 2, ctypes.addressof(shapes), None) == -2      # reference rows: S or N * S
