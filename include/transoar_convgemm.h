@@ -67,6 +67,9 @@ int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw,
                           int Cout, int MD, int MH, int MW, int src_stride,
                           unsigned taps_d, unsigned taps_h, unsigned taps_w, int chunks, int taps_out, void* hip_stream);
 
+/* nn.Conv3d's fp32 weight (Cout, Cin, 3,3,3) -> wk (27, Cout, Cin) bf16 and, if wkt != NULL, wkt (27, Cin, Cout) bf16 */
+int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cout, int Cin, void* hip_stream);
+
 int transoar_convgemm_abi_version(void);
 
 #ifdef __cplusplus

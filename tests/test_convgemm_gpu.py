@@ -58,3 +58,18 @@ def test_linear_wgrad_is_the_one_tap_case(t, k, nn_):
     want = gy.float().t() @ x.float()
     got = G.linear_wgrad(x, gy)
     assert relerr(got, want) <= 2e-3
+
+
+@pytest.mark.parametrize("co,ci", [(48, 24), (96, 96), (200, 56), (768, 384)])
+def test_filter_pack_kernel(co, ci):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    import os
+    w = torch.randn(co, ci, 3, 3, 3, device="cuda")
+    os.environ["TRANSOAR_CONV_PACK_HIP"] = "1"
+    try:
+        wk, wkt = G.pack_both(w)
+    finally:
+        del os.environ["TRANSOAR_CONV_PACK_HIP"]
+    assert torch.equal(wk, G.pack_fwd(w)) and torch.equal(wkt, G.pack_dgrad(w))

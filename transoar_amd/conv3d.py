@@ -226,6 +226,7 @@ class _Conv3dK3(torch.autograd.Function):
         # (MIOpen's weight gradient) mistakes it for a channels-last problem
         xb = x.to(torch.bfloat16).contiguous() if x.shape[1] == 1 else _as_ndhwc(x)
         ci = xb.shape[1]
+        wkt = None
         if ci == 1:
             # one input channel: through the MFMA implicit GEMM with the channel axis zero-padded to 8
             # (K = 27 taps x 8); the scalar stencil kernel (transoar_conv3d_c1_forward) is VALU-bound at a
@@ -242,10 +243,15 @@ class _Conv3dK3(torch.autograd.Function):
                 y = conv3d_k3_forward(x8.permute(0, 4, 1, 2, 3), _pack_taps(w8), b32, stride)
         elif _use_gemm(ci, weight.shape[0], stride):
             # 48 channels and up (and the strided 24 -> 48 layer): LDS-tiled implicit GEMM (csrc/conv_gemm.hip)
-            y = _cg.conv_forward(xb, _cg.pack_fwd(weight), bias.float() if bias is not None else None, stride)
+            # both filter packs in one pass over the fp32 weight when the backward will want the second one
+            if weight.requires_grad or x.requires_grad:
+                wk, wkt = _cg.pack_both(weight)
+            else:
+                wk = _cg.pack_fwd(weight)
+            y = _cg.conv_forward(xb, wk, bias.float() if bias is not None else None, stride)
         else:
             y = conv3d_k3_forward(xb, _pack_taps(weight), bias.float() if bias is not None else None, stride)
-        ctx.save_for_backward(xb, weight)
+        ctx.save_for_backward(xb, weight, wkt)
         ctx.stride, ctx.has_bias = stride, bias is not None
         return y
 
@@ -259,7 +265,7 @@ class _Conv3dK3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xb, weight = ctx.saved_tensors
+        xb, weight, wkt = ctx.saved_tensors
         gyb = _as_ndhwc(gy)
         gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -267,7 +273,7 @@ class _Conv3dK3(torch.autograd.Function):
         hip_x = need_x and (gemm or ctx.stride == 1 or _Conv3dK3.hip_dgrad_strided)
         hip_w = need_w and _Conv3dK3.hip_wgrad
         if hip_x and gemm:
-            gx = _cg.conv_dgrad(gyb, _cg.pack_dgrad(weight), ctx.stride, tuple(xb.shape[2:]))
+            gx = _cg.conv_dgrad(gyb, wkt if wkt is not None else _cg.pack_dgrad(weight), ctx.stride, tuple(xb.shape[2:]))
         elif hip_x:
             # data gradient = convolution of dy with the flipped, in/out-swapped filter
             wt = weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, weight.shape[1], weight.shape[0])

@@ -29,6 +29,8 @@ def _load():
     lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
     lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
     lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i, i]
+    lib.transoar_conv3d_pack.restype = i
+    lib.transoar_conv3d_pack.argtypes = [p, p, p, i, i, p]
     lib.transoar_convgemm_abi_version.restype = i
     if lib.transoar_convgemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -75,6 +77,20 @@ def pack_dgrad(weight):
     """(Cout, Cin, 3,3,3) -> (27, Cin, Cout) bf16: the data gradient contracts over Cout."""
     co, ci = weight.shape[:2]
     return weight.permute(2, 3, 4, 1, 0).reshape(27, ci, co).to(torch.bfloat16).contiguous()
+
+
+def pack_both(weight):
+    """fp32 contiguous (Cout, Cin, 3,3,3) -> (wk (27, Cout, Cin), wkt (27, Cin, Cout)) bf16.  TRANSOAR_CONV_PACK_HIP=1: in one
+    kernel (transoar_conv3d_pack) -- measured 0.5 ms per step SLOWER than torch's two permute-and-cast copies (its 32 x 32
+    tiles are 2 to 576 blocks per layer: the small layers do not fill the chip), so it is off by default."""
+    co, ci = weight.shape[:2]
+    if weight.dtype != torch.float32 or not weight.is_contiguous() or not os.environ.get("TRANSOAR_CONV_PACK_HIP"):
+        return pack_fwd(weight), pack_dgrad(weight)
+    wk = torch.empty((27, co, ci), dtype=torch.bfloat16, device=weight.device)
+    wkt = torch.empty((27, ci, co), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _check(lib.transoar_conv3d_pack(weight.data_ptr(), wk.data_ptr(), wkt.data_ptr(), co, ci, _stream()), "transoar_conv3d_pack")
+    return wk, wkt
 
 
 def _split_for(tiles, k_steps):

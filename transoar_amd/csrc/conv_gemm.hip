@@ -508,6 +508,31 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
     if (e0 * slabs + idx < coci * slabs) dw[e0 * slabs + idx] = sh[idx];
 }
 
+// nn.Conv3d's fp32 weight (Cout, Cin, 27) -> the two bf16 filter packs of the kernels above in one pass: wk (27, Cout, Cin)
+// for the forward and the weight gradient's layout, wkt (27, Cin, Cout) for the data gradient.  A block turns a 32 x 32
+// (co, ci) tile through LDS so that both outputs leave as contiguous 64-byte runs.
+__global__ __launch_bounds__(256) void conv3d_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wk,
+                                                          unsigned short* __restrict__ wkt, int co_n, int ci_n) {
+  __shared__ unsigned short sh[27][32][33];
+  const int tiles_ci = (ci_n + 31) / 32;
+  const int co0 = (blockIdx.x / tiles_ci) * 32, ci0 = (blockIdx.x % tiles_ci) * 32;
+  // 32 x 32 pairs x 27 taps = 27648 floats; the 27 taps of a pair are contiguous, pairs along ci are 27 floats apart
+  for (int idx = threadIdx.x; idx < 32 * 32 * 27; idx += 256) {
+    const int col = idx % (32 * 27), a = idx / (32 * 27);          // a: co inside the tile; col: (ci, tap) run of 864 floats
+    const int b = col / 27, tap = col - b * 27;
+    const int co = co0 + a, ci = ci0 + b;
+    float v = 0.f;
+    if (co < co_n && ci < ci_n) v = w[(static_cast<long>(co) * ci_n + ci) * 27 + tap];
+    sh[tap][a][b] = f32_to_bf16(v);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 27 * 32 * 32; idx += 256) {
+    const int x = idx & 31, y = (idx >> 5) & 31, tap = idx >> 10;
+    if (co0 + y < co_n && ci0 + x < ci_n) wk[(static_cast<long>(tap) * co_n + co0 + y) * ci_n + ci0 + x] = sh[tap][y][x];
+    if (wkt != nullptr && ci0 + y < ci_n && co0 + x < co_n) wkt[(static_cast<long>(tap) * ci_n + ci0 + y) * co_n + co0 + x] = sh[tap][x][y];
+  }
+}
+
 int check_geom(const ConvGeom& g) {
   if (g.N <= 0 || g.SD <= 0 || g.SH <= 0 || g.SW <= 0 || g.MD <= 0 || g.MH <= 0 || g.MW <= 0 || g.OD <= 0 || g.OH <= 0 || g.OW <= 0 ||
       g.Cin <= 0 || g.Cout <= 0 || (g.Cin & 7) || (g.Cout & 7) || g.src_stride < 1 || g.src_stride > 2 || g.out_stride < 1 || g.out_stride > 2)
@@ -606,6 +631,15 @@ extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part,
                        static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb);
   const long coci = static_cast<long>(Cout) * Cin;
   hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((coci + 31) / 32)), dim3(256), 0, st, part, dw, chunks, taps_out, coci);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cout, int Cin, void* hip_stream) {
+  if (!w || !wk) return TRANSOAR_CONVGEMM_ERR_NULL;
+  if (Cout <= 0 || Cin <= 0) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const int blocks = ((Cout + 31) / 32) * ((Cin + 31) / 32);
+  hipLaunchKernelGGL(conv3d_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), w,
+                     static_cast<unsigned short*>(wk), static_cast<unsigned short*>(wkt), Cout, Cin);
   return static_cast<int>(hipGetLastError());
 }
 

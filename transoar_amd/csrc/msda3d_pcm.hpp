@@ -294,7 +294,13 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const unsigned pk = __builtin_amdgcn_perm(static_cast<unsigned>(i0[1][k]), static_cast<unsigned>(i0[0][k]), 0x05040100u);
-      const unsigned ng = __builtin_bit_cast(unsigned, -__builtin_bit_cast(s16x2, pk));
+      // highest corner voxel a point really touches along this axis: i0 + 1 only if its fraction is non-zero.  On integer
+      // pixel coordinates (the module's initial state: offsets of whole voxels, ms_deform_attn.py:67-82) seven of the
+      // eight corners have weight zero; they then do not widen the box (SURVEY appendix A's fast path) -- their entries
+      // go to the spare slot below
+      const int t0 = i0[0][k] + (fl[0][k == 0 ? 0 : k == 1 ? 1 : 2] > 0.f ? 1 : 0), t1 = i0[1][k] + (fl[1][k == 0 ? 0 : k == 1 ? 1 : 2] > 0.f ? 1 : 0);
+      const unsigned tp = __builtin_amdgcn_perm(static_cast<unsigned>(t1), static_cast<unsigned>(t0), 0x05040100u);
+      const unsigned ng = __builtin_bit_cast(unsigned, -__builtin_bit_cast(s16x2, tp));
       // a skipped point is neutral (32767) in both
       mn[k] = half_min_pk16(static_cast<int>((pk & okmask) | (0x7fff7fffu & ~okmask)));
       mx[k] = half_min_pk16(static_cast<int>((ng & okmask) | (0x7fff7fffu & ~okmask)));
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
       lo3[k] = (l & 1) ? (a >> 16) : static_cast<short>(a);
       hi3[k] = -((l & 1) ? (c >> 16) : static_cast<int>(static_cast<short>(c)));
     }
-    box[l] = PcmBox{lo3[0], lo3[1], lo3[2], hi3[0] - lo3[0] + 2, hi3[1] - lo3[1] + 2, hi3[2] - lo3[2] + 2};
+    box[l] = PcmBox{lo3[0], lo3[1], lo3[2], hi3[0] - lo3[0] + 1, hi3[1] - lo3[1] + 1, hi3[2] - lo3[2] + 1};
     mode[l] = (l >= L || lo3[0] == 32767) ? 0 : (box[l].TD * box[l].TH * box[l].TW <= kPcmBoxRows ? 1 : 2);
   }
 
@@ -441,7 +447,8 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const unsigned t = static_cast<unsigned>(col[c] - k0);
-          wad[c] = t < static_cast<unsigned>(KW) ? static_cast<int>(t) : spare;
+          // a zero weight (a corner whose fraction is zero, a skipped point) may lie outside the box: never into a real slot
+          wad[c] = (t < static_cast<unsigned>(KW) && wq[l][c] != 0u) ? static_cast<int>(t) : spare;
           wcol[wad[c]] = wq[l][c];
         }
       }

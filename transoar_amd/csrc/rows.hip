@@ -105,19 +105,33 @@ __global__ __launch_bounds__(256) void colsum_partial(const u32x4r* __restrict__
   }
 }
 
-// 32 columns per workgroup, 8 row lanes of 128 partials each, the 8 sums meet in LDS
-__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ partials, float* __restrict__ out, int cols) {
-  __shared__ float sh[8][32];
+// 32 columns per workgroup, 32 row lanes of 32 partials each, the 32 sums meet in LDS
+__global__ __launch_bounds__(1024) void colsum_final(const float* __restrict__ partials, float* __restrict__ out, int cols) {
+  // 32 groups of 32 columns: a thread adds kColsumBlocks / 32 partial rows, eight loads in flight at a time (with 8
+  // groups and a serial chain of 128 dependent L2 round trips this pass took 35 us -- as long as the reduction itself)
+  __shared__ float sh[32][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  float a = 0.f;
-  if (c < cols)
-    for (int b = grp; b < kColsumBlocks; b += 8) a += partials[static_cast<long>(b) * cols + c];
-  sh[grp][cl] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    const float* p = partials + static_cast<long>(grp) * cols + c;
+    const long step = 32L * cols;
+    int b = grp;
+    for (; b + 96 < kColsumBlocks; b += 128) {
+      a0 += p[0]; a1 += p[step]; a2 += p[2 * step]; a3 += p[3 * step];
+      p += 4 * step;
+    }
+    for (; b < kColsumBlocks; b += 32) {
+      a0 += *p;
+      p += step;
+    }
+  }
+  sh[grp][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (grp == 0 && c < cols) {
+    float a = 0.f;
 #pragma unroll
-    for (int g = 1; g < 8; ++g) a += sh[g][cl];
+    for (int g = 0; g < 32; ++g) a += sh[g][cl];
     out[c] = a;
   }
 }
@@ -163,6 +177,6 @@ extern "C" int transoar_rows_colsum(const void* x, float* out, float* workspace,
   const int vpr = cols / 8, rpb = 256 / vpr;
   hipLaunchKernelGGL(colsum_partial, dim3(kColsumBlocks), dim3(256), 0, st, static_cast<const u32x4r*>(x), workspace, rows,
                      vpr, rpb);
-  hipLaunchKernelGGL(colsum_final, dim3((cols + 31) / 32), dim3(256), 0, st, workspace, out, cols);
+  hipLaunchKernelGGL(colsum_final, dim3((cols + 31) / 32), dim3(1024), 0, st, workspace, out, cols);
   return static_cast<int>(hipGetLastError());
 }
