@@ -55,7 +55,7 @@ TAPS_ONE = _taps([(0, 1)])
 
 # launches with fewer output tiles than this split their K steps (fp32 atomics + a cast pass)
 SPLIT_BELOW_TILES = 384
-WGRAD_BLOCKS = 1024
+WGRAD_BLOCKS = 512          # workgroups of a weight-gradient launch: one resident set (2 per CU); 2x for very long or very wide problems
 
 
 def _check(rc, what):
@@ -160,7 +160,8 @@ def _wgrad(x2, gy2, geom, taps, taps_out, out_shape):
     bt = 64 if (ci <= 64 and co <= 64) else 128
     tiles = nt * ((co + bt - 1) // bt) * ((ci + bt - 1) // bt)
     rows = n * md * mh * mw
-    chunks = max(1, min(WGRAD_BLOCKS // tiles, rows // 1024 if rows >= 1024 else 1))      # >= 16 K steps of 64 rows per block
+    budget = WGRAD_BLOCKS * (2 if (rows >= (1 << 20) or tiles >= 64) else 1)      # tools/tune_wgrad.py
+    chunks = max(1, min(budget // tiles, rows // 1024 if rows >= 1024 else 1))      # >= 16 K steps of 64 rows per block
     part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks, taps_out), dtype=torch.float32, device=x2.device)
     dw = torch.empty(out_shape, dtype=torch.float32, device=x2.device)
     with torch.cuda.device(x2.device):

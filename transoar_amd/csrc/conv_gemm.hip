@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void conv3d_finish_kernel(const float* __restr
 // with plain stores into its own chunk's partial map (no atomics); conv3d_wgrad_reduce sums the chunks.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int WK = 64;                      // voxel rows per K step
+constexpr int kSegRows = 2048;              // voxel rows whose source offsets are tabulated at a time
 
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
@@ -361,20 +362,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     unsigned tp_d, unsigned tp_h, unsigned tp_w, int chunks, int rows_per_chunk, int tiles_co, int tiles_ci, int slabs,
     unsigned dy_bytes, unsigned x_bytes) {
   constexpr int BT = 64 * TW;                // block tile side (channels)
-  constexpr int WP = 2 * BT + 16;            // bytes per staged row: BT channels + padding (bank spread for the transposing reads)
+  constexpr int WP = 2 * BT;                 // bytes per staged row: BT channels, no padding -- the 64-byte windows the transposing reads
+                                             // take out of 4 consecutive rows are XOR-swizzled over the banks instead (row_swz)
   constexpr int PR = 8 * TW;                 // 16-byte pieces per row
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * WK * WP];       // [stage]: dY tile, then X tile
+  __shared__ unsigned xrow[kSegRows];                                              // source row offsets of a segment of voxel rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nd = taps_count(tp_d), nh = taps_count(tp_h), nw = taps_count(tp_w);
   const int ntaps = nd * nh * nw;
-  // block -> (chunk, ci tile, co tile, tap): chunk fastest so that neighbouring blocks read neighbouring voxels
-  long bid = blockIdx.x;
-  const int chunk = static_cast<int>(bid % chunks); bid /= chunks;
+  // block -> (ci tile, co tile, tap, chunk), chunk SLOWEST and every XCD walking a contiguous range: the workgroups that
+  // run at the same time on an XCD are the tiles and taps of the same few voxel chunks, whose dY and x rows they share
+  // through that XCD's L2.  (With the chunk fastest, co-resident workgroups shared nothing and the projection shapes ran
+  // at the HBM rate of their re-reads: 2.9 GB per call for 234 000 x 384 x 1024.)
+  long bid = xcd_contiguous(blockIdx.x, static_cast<long>(chunks) * tiles_ci * tiles_co * ntaps);
+  if (bid < 0) return;
   const int tci = static_cast<int>(bid % tiles_ci); bid /= tiles_ci;
   const int tco = static_cast<int>(bid % tiles_co); bid /= tiles_co;
-  const int tap = static_cast<int>(bid);
-  if (tap >= ntaps) return;
+  const int tap = static_cast<int>(bid % ntaps); bid /= ntaps;
+  const int chunk = static_cast<int>(bid);
   const int ed = tap / (nh * nw), r_ = tap - ed * nh * nw, eh = r_ / nw, ew = r_ - eh * nw;
   const int dd = taps_delta(tp_d, ed), dh = taps_delta(tp_h, eh), dw = taps_delta(tp_w, ew);
   const int slab = (taps_t(tp_d, ed) * 3 + taps_t(tp_h, eh)) * 3 + taps_t(tp_w, ew);
@@ -388,35 +394,50 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   constexpr int NS = WK * PR / 256, RS = 256 / PR;                // pieces per thread, rows per pass
   const int s_piece = tid % PR, s_row = tid / PR;                 // rows s_row + RS i
   const bool co_ok = co0 + s_piece * 8 < g.Cout, ci_ok = ci0 + s_piece * 8 < g.Cin;
+  const unsigned y_col = co_ok ? static_cast<unsigned>(co0 + s_piece * 8) * 2u : 0x80000000u;
+  const unsigned x_col = ci_ok ? static_cast<unsigned>(ci0 + s_piece * 8) * 2u : 0x80000000u;
+  // The source row of every voxel row of a segment is worked out ONCE per workgroup into LDS (byte offset of the shifted x
+  // voxel's first channel, or an out-of-range marker for the padding): with the decomposition m -> (nb, md, mh, mw) done
+  // per K step and thread, the kernel issued 12.7 VALU instructions per MFMA and was VALU-bound (profiles/r03_wgrad_pmc.txt).
   const float inv_mw = 1.0f / static_cast<float>(g.MW), inv_mh = 1.0f / static_cast<float>(g.MH), inv_md = 1.0f / static_cast<float>(g.MD);
+  auto fill_rows = [&](int seg_beg, int seg_end) {
+    for (int m = seg_beg + tid; m < seg_end; m += 256) {
+      // m -> (nb, md, mh, mw) by float reciprocals: (q + 0.5) / n is >= 0.5 / n away from an integer, more than the
+      // float error for m < 2^21 (checked on the host)
+      const int r1 = static_cast<int>((static_cast<float>(m) + 0.5f) * inv_mw), mw = m - r1 * g.MW;
+      const int r2 = static_cast<int>((static_cast<float>(r1) + 0.5f) * inv_mh), mh = r1 - r2 * g.MH;
+      const int nb = static_cast<int>((static_cast<float>(r2) + 0.5f) * inv_md), md = r2 - nb * g.MD;
+      const int sd = md * g.src_stride + dd, sh = mh * g.src_stride + dh, sw = mw * g.src_stride + dw;
+      const bool ok = static_cast<unsigned>(sd) < static_cast<unsigned>(g.SD) && static_cast<unsigned>(sh) < static_cast<unsigned>(g.SH) &&
+                      static_cast<unsigned>(sw) < static_cast<unsigned>(g.SW);
+      xrow[m - seg_beg] = ok ? static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) * 2u : 0x80000000u;
+    }
+  };
+  // A transposing read takes a 64-byte window (32 channels) out of each of 4 consecutive rows: 4 x 16 banks.  With
+  // 256-byte rows all four start in the same bank, with 128-byte rows every second one: the 16-byte pieces of a row are
+  // stored XORed with 4 * (row & 3) (resp. 4 * ((row >> 1) & 1)), which turns the four windows into a tiling of the 64
+  // banks.  (With 16 bytes of row padding instead, the windows overlapped 4-fold: 58 % of the LDS cycles were conflicts.)
+  auto row_swz = [](int r) -> int { return TW == 2 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
   u32x4 ry0[NS], rx0[NS], ry1[NS], rx1[NS];
+  int seg0 = 0, seg1 = 0;                                         // rows of the current segment
   auto load_step = [&](int m_base, u32x4 (&ry)[NS], u32x4 (&rxx)[NS]) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int m = m_base + s_row + RS * i;
-      unsigned yo = 0x80000000u, xo = 0x80000000u;
-      if (m < m_end) {
-        // m -> (nb, md, mh, mw) by float reciprocals: (q + 0.5) / n is >= 0.5 / n away from an integer, more than the
-        // float error for m < 2^21 (checked on the host); an integer division here would cost more than the K step's MFMAs
-        const int r1 = static_cast<int>((static_cast<float>(m) + 0.5f) * inv_mw), mw = m - r1 * g.MW;
-        const int r2 = static_cast<int>((static_cast<float>(r1) + 0.5f) * inv_mh), mh = r1 - r2 * g.MH;
-        const int nb = static_cast<int>((static_cast<float>(r2) + 0.5f) * inv_md), md = r2 - nb * g.MD;
-        const int sd = md * g.src_stride + dd, sh = mh * g.src_stride + dh, sw = mw * g.src_stride + dw;
-        if (co_ok) yo = (static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) + co0 + s_piece * 8) * 2u;
-        if (ci_ok && static_cast<unsigned>(sd) < static_cast<unsigned>(g.SD) && static_cast<unsigned>(sh) < static_cast<unsigned>(g.SH) &&
-            static_cast<unsigned>(sw) < static_cast<unsigned>(g.SW))
-          xo = (static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) + ci0 + s_piece * 8) * 2u;
-      }
-      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, yo, 0, 0);
-      rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0);
+      const bool in = m < seg1;
+      const unsigned xo = in ? xrow[m - seg0] : 0x80000000u;
+      // (a marker plus the column offset stays out of range: the buffers are < 2^31 bytes)
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, in ? static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) * 2u + y_col : 0x80000000u, 0, 0);
+      rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + x_col, 0, 0);
     }
   };
   auto store_step = [&](int stage, const u32x4 (&ry)[NS], const u32x4 (&rxx)[NS]) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int r = s_row + RS * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * WP + s_piece * 16]) = ry[i];
-      *reinterpret_cast<u32x4*>(&lds[stage][WK * WP + r * WP + s_piece * 16]) = rxx[i];
+      const int sp = (s_piece ^ row_swz(r)) * 16;
+      *reinterpret_cast<u32x4*>(&lds[stage][r * WP + sp]) = ry[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][WK * WP + r * WP + sp]) = rxx[i];
     }
   };
   f32x16 acc[TW][TW];          // [co tile][ci tile] of the wave's quadrant
@@ -431,8 +452,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   const int kg = lane >> 5;
   const int t_row = 8 * kg + ((lane & 15) >> 2), t_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int t_swz = row_swz(t_row) * 16;         // rows t_row, t_row + 4, + 16 k16 share it
   auto frag = [&](const unsigned char* tile, int k16, int ch0) -> s16x8 {
-    const unsigned char* p = tile + (k16 * 16 + t_row) * WP + (ch0 + t_ch) * 2;
+    const unsigned char* p = tile + (k16 * 16 + t_row) * WP + (((ch0 + t_ch) * 2) ^ t_swz);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WP));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -454,19 +476,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
         for (int b = 0; b < TW; ++b) acc[a][b] = mfma(fy[a], fx[b], acc[a][b]);      // D[co][ci] += dY[k][co] X[k][ci]
     }
   };
-  const int steps = (m_end - m_beg + WK - 1) / WK;
-  if (steps > 0) {
-    load_step(m_beg, ry0, rx0);
-    if (steps > 1) load_step(m_beg + WK, ry1, rx1);
+  for (seg0 = m_beg; seg0 < m_end; seg0 += kSegRows) {
+    seg1 = min(m_end, seg0 + kSegRows);
+    __syncthreads();                                                // the previous segment's table and tiles are done with
+    fill_rows(seg0, seg1);
+    __syncthreads();
+    const int steps = (seg1 - seg0 + WK - 1) / WK;
+    load_step(seg0, ry0, rx0);
+    if (steps > 1) load_step(seg0 + WK, ry1, rx1);
     store_step(0, ry0, rx0);
     block_barrier();
     for (int s = 0; s < steps; s += 2) {
-      if (s + 2 < steps) load_step(m_beg + (s + 2) * WK, ry0, rx0);
+      if (s + 2 < steps) load_step(seg0 + (s + 2) * WK, ry0, rx0);
       compute(0);
       if (s + 1 < steps) store_step(1, ry1, rx1);
       block_barrier();
       if (s + 1 >= steps) break;
-      if (s + 3 < steps) load_step(m_beg + (s + 3) * WK, ry1, rx1);
+      if (s + 3 < steps) load_step(seg0 + (s + 3) * WK, ry1, rx1);
       compute(1);
       if (s + 2 < steps) store_step(0, ry0, rx0);
       block_barrier();
@@ -620,7 +646,7 @@ extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part,
   const bool small = Cin <= 64 && Cout <= 64;              // 64 x 64 tiles for the 24..64-channel layers
   const int bt = small ? 64 : 128;
   const int tiles_co = (Cout + bt - 1) / bt, tiles_ci = (Cin + bt - 1) / bt;
-  const long blocks = static_cast<long>(chunks) * tiles_ci * tiles_co * ntaps;
+  const long blocks = (static_cast<long>(chunks) * tiles_ci * tiles_co * ntaps + 7) / 8 * 8;
   if (blocks >= (1L << 31)) return TRANSOAR_CONVGEMM_ERR_DIM;
   const unsigned dyb = static_cast<unsigned>(M * Cout * 2), xb = static_cast<unsigned>(static_cast<long>(N) * SD * SH * SW * Cin * 2);
   if (small)

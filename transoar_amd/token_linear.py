@@ -46,11 +46,12 @@ def _chunks(tokens, n_out, n_in):
     return tokens // size, size
 
 
-# TRANSOAR_HIP_WGRAD=1: the hand-written voxel-major ("TN") GEMM of csrc/conv_gemm.hip (its one-tap case) instead of the
-# chunked hipBLASLt batch.  Measured at the 234 000-token shapes (tools/bench_gemm.py, profiles/r03_gemm_bench.jsonl):
-# 0.28 / 0.49 / 0.46 ms against 0.14 / 0.29 / 0.27 ms -- the batch stays the default for the projections; the
-# convolutions' weight gradients (27 taps, shifted operand) have no library counterpart and run on the kernel.
-USE_HIP_WGRAD = os.environ.get("TRANSOAR_HIP_WGRAD", "0") == "1"
+# The hand-written voxel-major ("TN") GEMM of csrc/conv_gemm.hip (its one-tap case).  At the 234 000-token shapes
+# (tools/bench_gemm.py, profiles/r03_gemm_bench.jsonl) it is within 5-13 % of round 2's chunked hipBLASLt batch on
+# 384 x 384 / 384 -> 1024 / 1024 -> 384 (0.16 / 0.31 / 0.31 ms against 0.15 / 0.29 / 0.28) and ahead on the stacked
+# 384 -> 576 projection and the FPN's 384 -> 3072 one (0.25 / 0.79 against 0.28 / 0.88): it is the default, so that no
+# library GEMM is left in the weight-gradient path; TRANSOAR_HIP_WGRAD=0 goes back to the batch.
+USE_HIP_WGRAD = os.environ.get("TRANSOAR_HIP_WGRAD", "1") == "1"
 
 
 def weight_grad(gy, x):
