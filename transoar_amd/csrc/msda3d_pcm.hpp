@@ -34,7 +34,8 @@
 namespace transoar {
 
 constexpr int kPcmKB = 32;                // value rows per K-block
-constexpr int kPcmVP = 144;               // bytes per staged row: 128 + 16 (spreads the transposing reads over the banks)
+constexpr int kPcmVP = 128;               // bytes per staged row, no padding: the 16-byte pieces of a row are stored XORed with 4 * ((row >> 1) & 1),
+                                          // which makes the four 64-byte windows a transposing read takes out of 4 consecutive rows tile the 64 banks
 constexpr int kPcmKW = 32;                // K-slots of a weight column: 32 (one staged block of rows) or 64 (two)
 constexpr int kPcmWP = kPcmKW + 4;        // dwords per weight column: 64 K-slots + 4 spares (one is used, by column: bank spread) for entries outside the block
 constexpr int kPcmBoxRows = 256;          // larger boxes: explicit (column, corner) slots instead (also 256 rows)
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
     unsigned n_units, const PcmConst* __restrict__ cst) {
   const BrickOrder& order = cst->order;
   constexpr int C = 64, KB = kPcmKB, KW = kPcmKW, VP = kPcmVP, WP = kPcmWP;
-  __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];        // staged rows; parameter block and output rows alias it
+  __shared__ __attribute__((aligned(128))) unsigned char vbuf[KB * VP];       // staged rows; parameter block and output rows alias it
   __shared__ __attribute__((aligned(16))) unsigned wbuf[32 * WP];            // [column][K-slot]: (hi << 16) | lo
 
   // XCD-contiguous work order (block b runs on XCD b % 8: each XCD walks one contiguous eighth)
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
   };
   // the 32 rows of one half of the 64: 4 x 16 bytes per lane; the 8 lanes that fetch a row get its offset through ds_bpermute
   const int st_row = lane >> 3, st_vec = lane & 7;
+  const int st_swz = (st_vec ^ ((st_row & 2) << 1)) * 16;         // rows it * 8 + st_row: bit 1 of the row = bit 1 of st_row
   auto issue_loads = [&](int row_off, int half, u32x4 (&pre)[4]) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -404,6 +406,8 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
   u32x4 pre[4];
   bool have_pre = false;
   int row_off = 0;
+  // byte offsets of the lane's two transposing reads inside a staged row (channel tiles 0 and 1), swizzled like the stores
+  const int tr_off0 = ((16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2) ^ ((((lane & 15) >> 2) & 2) << 5), tr_off1 = tr_off0 ^ 64;
   unsigned* const wcol = wbuf + n * WP;
   const int spare = KW + (n >> 3);            // the column's spare slot (entries outside the block): the 4 slots past the K-slots, so that the 32 columns' spares sit in 32 different banks
   static_for<0, kPcmLevels>([&](auto lc) {
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
       const int nch = (min(KB, R - hb * KB) + 15) >> 4;                   // 16-row chunks of this half: 1 or 2
       // ---- staged rows -> LDS
 #pragma unroll
-      for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+      for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_swz) = pre[it];
       if (nch > 1) {
 #pragma unroll
-        for (int it = 2; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_vec * 16) = pre[it];
+        for (int it = 2; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_swz) = pre[it];
       }
       // ---- the lane's four entries for the 64 rows that start here: slot inside the block, or the spare slot
       if (sub == 0) {
@@ -475,12 +479,13 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
         const u32x4 alo{__builtin_amdgcn_perm(p0[1], p0[0], 0x05040100u), __builtin_amdgcn_perm(p0[3], p0[2], 0x05040100u),
                         __builtin_amdgcn_perm(p1[1], p1[0], 0x05040100u), __builtin_amdgcn_perm(p1[3], p1[2], 0x05040100u)};
         // B = V: lane supplies row (lane & 15) >> 2 of its group's 4-row set, 4 channels; receives its channel's column
-        const unsigned char* vb = vbuf + (kc * 16 + 8 * kh + ((lane & 15) >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+        // rows kc*16 + 8 kh + r (and + 4), r = (lane & 15) >> 2: bit 1 of the row is bit 1 of r -> the lane's swizzle is constant
+        const unsigned char* vrow = vbuf + (kc * 16 + 8 * kh + ((lane & 15) >> 2)) * VP;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb));
-        const s16x4 b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 4 * VP));
-        const s16x4 b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 64));
-        const s16x4 b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 4 * VP + 64));
+        const s16x4 b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + tr_off0));
+        const s16x4 b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * VP + tr_off0));
+        const s16x4 b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + tr_off1));
+        const s16x4 b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * VP + tr_off1));
         const s16x8 v0 = __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7);
         const s16x8 v1 = __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7);
         const s16x8 whi = __builtin_bit_cast(s16x8, ahi), wlo = __builtin_bit_cast(s16x8, alo);
