@@ -280,7 +280,7 @@ class _Conv3dK3(torch.autograd.Function):
             gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
         if need_w and ctx.stride == 1 and c1_wgrad_supported(xb, gyb):
             gw, hip_w = conv3d_c1_wgrad(xb, gyb).to(weight.dtype), True       # one input channel: MFMA over voxel chunks
-        elif need_w and ctx.stride == 1 and lds_wgrad_supported(xb, gyb):
+        elif need_w and ctx.stride == 1 and lds_wgrad_supported(xb, gyb) and (max(xb.shape[1], gyb.shape[1]) <= 32 or gyb.numel() // gyb.shape[1] >= (1 << 21)):
             gw, hip_w = conv3d_k3_wgrad_lds(xb, gyb).to(weight.dtype), True   # few channels, 10^7 voxels: LDS-transposed MFMA
         elif need_w and xb.shape[1] % 8 == 0 and gyb.numel() // gyb.shape[1] < (1 << 21):
             gw, hip_w = _cg.conv_wgrad(xb, gyb, ctx.stride).to(weight.dtype), True     # voxel-major GEMM with transposing LDS reads

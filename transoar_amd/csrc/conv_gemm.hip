@@ -198,12 +198,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = s_row + 32 * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ (r & 7)) << 4)]) = ra[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int r = s_row + 32 * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][kTile + r * 128 + ((s_piece ^ (r & 7)) << 4)]) = rb[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][kTile + r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = rb[i];
     }
   };
 
@@ -222,12 +222,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rm = wm * 64 + i * 32 + fr;
-      fa_off[k4][i] = rm * 128 + ((piece ^ (rm & 7)) << 4);
+      fa_off[k4][i] = rm * 128 + ((piece ^ ((rm >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int rn = wn * 32 * TN + i * 32 + fr;
-      fb_off[k4][i] = rn * 128 + ((piece ^ (rn & 7)) << 4);
+      fb_off[k4][i] = rn * 128 + ((piece ^ ((rn >> 1) & 7)) << 4);
     }
   }
   auto compute = [&](int stage) {

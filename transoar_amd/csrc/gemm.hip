@@ -8,7 +8,8 @@
 //   * 256 threads = 4 waves (2 x 2), block tile 128 x 128, K step 64; a wave owns 64 x 64 = 2 x 2 MFMA tiles
 //     of v_mfma_f32_32x32x16 (bf16 or f16), 16 MFMAs per K step;
 //   * operand tiles are [128 rows][64 K] = 128-byte rows in LDS with the 16-byte pieces XOR-swizzled by the
-//     row (piece ^ (row & 7)): the ds_read_b128 of an MFMA fragment (32 rows, one piece each) spreads over all
+//     row (piece ^ ((row >> 1) & 7)); with row & 7, as in round 2, rows 8 apart shared their four banks and a third of
+//     the LDS cycles were conflicts (ds_read_b128 serves lanes {0-3,12-15,20-27} together): the ds_read_b128 of an MFMA fragment (32 rows, one piece each) spreads over all
 //     banks; two LDS stages, global -> registers -> LDS staging with the next tile's loads in flight during the
 //     MFMAs (one barrier per K step);
 //   * the MFMAs are issued with the WEIGHT tile as the A operand, so D = C^T tiles come out [n][m]: a lane
@@ -121,12 +122,12 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = s_row + RPP * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ (r & 7)) << 4)]) = ra_regs[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = ra_regs[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int r = s_row + RPP * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][kATileBytes + r * 128 + ((s_piece ^ (r & 7)) << 4)]) = rb_regs[i];
+      *reinterpret_cast<u32x4*>(&lds[stage][kATileBytes + r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = rb_regs[i];
     }
   };
 
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rm = wm * 64 + i * 32 + fr, rn = wn * 64 + i * 32 + fr, piece = 2 * ks + kg;
-      fa_off[ks][i] = rm * 128 + ((piece ^ (rm & 7)) << 4);
-      fb_off[ks][i] = rn * 128 + ((piece ^ (rn & 7)) << 4);
+      fa_off[ks][i] = rm * 128 + ((piece ^ ((rm >> 1) & 7)) << 4);
+      fb_off[ks][i] = rn * 128 + ((piece ^ ((rn >> 1) & 7)) << 4);
     }
   auto compute = [&](int stage) {
     const unsigned char* ta = lds[stage];
