@@ -11,17 +11,20 @@
 //       out_stride * m + out_parity of the output map.  One kernel, three uses:
 //         forward          row space = output map, stride 1 or 2, taps = all 27 with delta = t - 1
 //         data gradient    of a stride-1 layer: the same with the flipped, in/out-swapped filter (host packs it)
-//         data gradient    of a stride-2 layer: eight launches, one per parity class (pd, ph, pw) of the dx voxels --
-//                          a dx voxel of even coordinate sees tap 1 of dy voxel x/2, one of odd coordinate taps 0
-//                          and 2 of dy voxels (x+1)/2 and (x-1)/2: row space = the class's voxels, 1/2/4/8 taps,
-//                          source = dy at stride 1, output rows strided by 2 into dx
+//         data gradient    of a stride-2 layer: ONE launch over the eight parity classes (pd, ph, pw) of the dx
+//                          voxels -- a dx voxel of even coordinate sees tap 1 of dy voxel x/2, one of odd coordinate
+//                          taps 0 and 2 of dy voxels (x+1)/2 and (x-1)/2: row space = the class's voxels, 1/2/4/8
+//                          taps, source = dy at stride 1, output rows strided by 2 into dx
+//       Launches with few tiles split K: every split stores its fp32 tile into its own partial map (no atomics) and
+//       conv3d_finish_kernel sums the maps, adds the bias and casts.
 //   transoar_conv3d_wgrad   dW[tap][co][ci] = sum_m dY[m][co] * X[src(m, tap)][ci]  (msda-style "TN" GEMM: both
 //       operands have the contraction axis (voxels) as their slow axis; tiles are staged K-major and read with the
-//       transposing ds_read_b64_tr_b16), split over voxel ranges, fp32 atomics into dW.  With taps = 1 and no
-//       shift it is the weight gradient of a token projection (dW = dY^T X, decoder_blocks.py:157-174).
+//       transposing ds_read_b64_tr_b16), split over voxel chunks; each chunk stores its fp32 tile into its own
+//       partial map and conv3d_wgrad_reduce_kernel sums them into (Cout, Cin, 27) through an LDS turn.  With taps = 1
+//       and no shift it is the weight gradient of a token projection (dW = dY^T X, decoder_blocks.py:157-174).
 //
 // GEMM machinery = gemm.hip's: 256 threads = 2 x 2 waves, block tile 128 x 128, K step 64, v_mfma_f32_32x32x16_bf16,
-// operand tiles as 128-byte rows in LDS with XOR-swizzled 16-byte pieces, two LDS stages + two register sets, raw
+// operand tiles as 128-byte rows in LDS with 16-byte pieces XOR-swizzled by (row >> 1) & 7, two LDS stages + two register sets, raw
 // buffer loads whose out-of-range lanes read zeros.  K is the flattened (tap, channel) axis in pieces of 8
 // channels: a K step of 64 may straddle two taps (Cin = 48, 96 ...), every thread resolves its own piece's tap.
 #include <hip/hip_runtime.h>
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   const unsigned x_col = ci_ok ? static_cast<unsigned>(ci0 + s_piece * 8) * 2u : 0x80000000u;
   // The source row of every voxel row of a segment is worked out ONCE per workgroup into LDS (byte offset of the shifted x
   // voxel's first channel, or an out-of-range marker for the padding): with the decomposition m -> (nb, md, mh, mw) done
-  // per K step and thread, the kernel issued 12.7 VALU instructions per MFMA and was VALU-bound (profiles/r03_wgrad_pmc.txt).
+  // per K step and thread, the kernel issued 12.7 VALU instructions per MFMA and was VALU-bound (profiles/r03_conv_pmc.txt).
   const float inv_mw = 1.0f / static_cast<float>(g.MW), inv_mh = 1.0f / static_cast<float>(g.MH), inv_md = 1.0f / static_cast<float>(g.MD);
   auto fill_rows = [&](int seg_beg, int seg_end) {
     for (int m = seg_beg + tid; m < seg_end; m += 256) {
