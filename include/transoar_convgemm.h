@@ -55,6 +55,16 @@ int transoar_conv3d_igemm(const void* x, const void* wk, const float* bias, void
 int transoar_conv3d_finish(const float* y32, const float* bias, void* y, long rows, int cout, int split, void* hip_stream);
 
 /*
+ * Data gradient of a stride-2 / pad-1 layer with few input channels (Cin <= 32, Cout = 16, 32 or 48: the 24 -> 48 layer
+ * that opens stage 1, encoder_blocks.py:28-51 with stride 2): dx (N, D, H, W, Cin) from dy (N, OD, OH, OW, Cout) and
+ * wkt (27, Cin, Cout); D = 2 OD or 2 OD - 1 (same for H, W).  One workgroup computes all eight parity classes of a
+ * 4 x 8 x 16 dx tile from the dy halo in LDS and writes it as whole lines (HBM bound; transoar_conv3d_igemm with
+ * classes = 1 is the general form).  Same result up to the order of the fp32 sums.
+ */
+int transoar_conv3d_dgrad_s2_halo(const void* dy, const void* wkt, void* dx, int N, int OD, int OH, int OW, int D, int H, int W,
+                                  int Cin, int Cout, void* hip_stream);
+
+/*
  * dw[co][ci][tap] (taps_out = 27: nn.Conv3d's weight layout (Cout, Cin, 3,3,3)) or dw[co][ci] (taps_out = 1: the one
  * tap of the lists, nn.Linear's (out, in)) = sum_m dy[m][co] * x[src(m, tap)][ci]          (fp32, written completely)
  *   rows m over (N, MD, MH, MW) = the voxels of dy (Cout channels); x is the source map (N, SD, SH, SW, Cin).

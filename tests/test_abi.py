@@ -147,6 +147,12 @@ def test_convgemm_and_fused_gather_argument_errors():
     w.argtypes = [p] * 4 + [i] * 10 + [u] * 3 + [i, i, p]
     assert w(p16, p16, None, p16, 1, 4, 4, 8, 16, 16, 4, 4, 8, 1, taps, taps, taps, 4, 27, None) == -1
     assert w(p16, p16, p16, p16, 1, 4, 4, 8, 16, 16, 4, 4, 8, 1, taps, taps, taps, 4, 5, None) == -2       # taps_out is 1 or 27
+    h = cg.transoar_conv3d_dgrad_s2_halo
+    h.argtypes = [p, p, p] + [i] * 9 + [p]
+    assert h(p16, None, p16, 1, 4, 4, 8, 8, 8, 16, 24, 48, None) == -1
+    assert h(p16, p16, p16, 1, 4, 4, 8, 8, 8, 16, 40, 48, None) == -2        # Cin <= 32
+    assert h(p16, p16, p16, 1, 4, 4, 8, 8, 8, 16, 24, 96, None) == -2        # Cout 16 / 32 / 48
+    assert h(p16, p16, p16, 1, 4, 4, 8, 8, 8, 14, 24, 48, None) == -2        # W = 2 OW or 2 OW - 1
     cg.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
     assert cg.transoar_conv3d_wgrad_part_floats(96, 96, 10, 27) == 27 * 96 * 96 * 10
 

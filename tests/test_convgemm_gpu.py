@@ -47,6 +47,30 @@ def test_conv_gemm_forward_dgrad_wgrad(case, split):
     assert relerr(gw, wr.grad) <= 2e-3
 
 
+@pytest.mark.parametrize("case", [(1, 24, 48, 8, 8, 16), (2, 24, 48, 7, 9, 15), (1, 8, 16, 5, 6, 18), (1, 32, 32, 9, 8, 17),
+                                  (2, 16, 48, 12, 10, 20), (1, 24, 48, 20, 24, 48)])
+def test_stride2_dgrad_halo_kernel(case):
+    """transoar_conv3d_dgrad_s2_halo (few input channels: all eight parity classes of a dx tile in one workgroup) against
+    torch's fp32 data gradient and against the general parity-class launch; odd sizes: D = 2 OD - 1, partial tiles."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    n, ci, co, d, h, w = case
+    torch.manual_seed(ci + co + d)
+    xr = torch.zeros(n, ci, d, h, w, device="cuda", requires_grad=True)
+    wt = (torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.1).to(torch.bfloat16).float()
+    yr = F.conv3d(xr, wt, None, stride=2, padding=1)
+    g = torch.randn_like(yr).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    yr.backward(g.float())
+    wkt = G.pack_dgrad(wt)
+    assert G.DGRAD_S2_HALO
+    gx = G.conv_dgrad(g, wkt, 2, (d, h, w))
+    general = G.conv_dgrad(g, wkt, 2, (d, h, w), split=1)
+    assert gx.is_contiguous(memory_format=torch.channels_last_3d)
+    assert relerr(gx, xr.grad) <= 2.0 ** -7
+    assert relerr(gx, general) <= 2.0 ** -7
+
+
 @pytest.mark.parametrize("t,k,nn_", [(1000, 384, 384), (4097, 384, 1024), (333, 1024, 384), (5000, 48, 64)])
 def test_linear_wgrad_is_the_one_tap_case(t, k, nn_):
     if not torch.cuda.is_available():

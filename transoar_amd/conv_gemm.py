@@ -1,7 +1,8 @@
 """ctypes binding and autograd shim of the LDS-tiled implicit-GEMM convolution kernels (C ABI:
 include/transoar_convgemm.h): the 3x3x3 convolutions of the encoder stages from 48 channels up and of the FPN `out`
 layers (encoder_blocks.py:28-51, attn_fpn.py:65-73,126), forward, data gradient (stride 1: one launch with the
-mirrored tap list; stride 2: eight launches, one per parity class of the dx voxels) and weight gradient -- and the
+mirrored tap list; stride 2: the eight parity classes of the dx voxels in one launch -- up to 32 input channels the
+halo-tile kernel that writes dx as whole lines) and weight gradient -- and the
 weight gradient of a token projection as the one-tap case.  No fallback: the library must be built."""
 import ctypes
 import os
@@ -12,7 +13,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_convgemm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 CL3D = torch.channels_last_3d
 
 
@@ -29,6 +30,8 @@ def _load():
     lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
     lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
     lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i, i]
+    lib.transoar_conv3d_dgrad_s2_halo.restype = i
+    lib.transoar_conv3d_dgrad_s2_halo.argtypes = [p, p, p] + [i] * 9 + [p]
     lib.transoar_conv3d_pack.restype = i
     lib.transoar_conv3d_pack.argtypes = [p, p, p, i, i, p]
     lib.transoar_convgemm_abi_version.restype = i
@@ -53,8 +56,9 @@ TAPS_DGRAD1 = _taps([(1, 0), (0, 1), (-1, 2)])     # source = m + 1 - t
 TAPS_PARITY = (_taps([(0, 1)]), _taps([(1, 0), (0, 2)]))     # dx voxel 2m + p: p = 0 sees tap 1 of dy m; p = 1 taps 0, 2 of dy m+1, m
 TAPS_ONE = _taps([(0, 1)])
 
-# launches with fewer output tiles than this split their K steps (fp32 atomics + a cast pass)
+# launches with fewer output tiles than this split their K steps (per-split partial maps + a finish pass)
 SPLIT_BELOW_TILES = 384
+DGRAD_S2_HALO = os.environ.get("TRANSOAR_DGRAD_S2_HALO", "1") != "0"
 WGRAD_BLOCKS = 512          # workgroups of a weight-gradient launch: one resident set (2 per CU); 2x for very long or very wide problems
 
 
@@ -144,6 +148,12 @@ def conv_dgrad(gy, wkt, stride, in_dims, split=None):
         if split is None:
             split = _split_for(_tiles(n * d * h * w, ci), (27 * co + 63) // 64)
         _igemm(gy, wkt, None, gx, (od, oh, ow), co, ci, (d, h, w), 1, (d, h, w), 1, (0, 0, 0), (TAPS_DGRAD1,) * 3, n, split)
+        return gx
+    if split is None and DGRAD_S2_HALO and ci <= 32 and co in (16, 32, 48):
+        # few input channels, full-resolution dx: one workgroup computes all eight parity classes of a dx tile (HBM bound)
+        with torch.cuda.device(gy.device):
+            _check(lib.transoar_conv3d_dgrad_s2_halo(gy.data_ptr(), wkt.data_ptr(), gx.data_ptr(), n, od, oh, ow, d, h, w, ci, co, _stream()),
+                   "transoar_conv3d_dgrad_s2_halo")
         return gx
     # stride 2: the eight parity classes (pd, ph, pw) of the dx voxels in one launch: 1, 2, 4 or 8 taps each
     if split is None:

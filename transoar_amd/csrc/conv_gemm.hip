@@ -562,6 +562,8 @@ __global__ __launch_bounds__(256) void conv3d_pack_kernel(const float* __restric
   }
 }
 
+#include "conv_dgrad_s2.hpp"
+
 int check_geom(const ConvGeom& g) {
   if (g.N <= 0 || g.SD <= 0 || g.SH <= 0 || g.SW <= 0 || g.MD <= 0 || g.MH <= 0 || g.MW <= 0 || g.OD <= 0 || g.OH <= 0 || g.OW <= 0 ||
       g.Cin <= 0 || g.Cout <= 0 || (g.Cin & 7) || (g.Cout & 7) || g.src_stride < 1 || g.src_stride > 2 || g.out_stride < 1 || g.out_stride > 2)
@@ -614,6 +616,29 @@ extern "C" int transoar_conv3d_igemm(const void* x, const void* wk, const float*
     hipLaunchKernelGGL(conv3d_igemm_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(x),
                        static_cast<const unsigned short*>(wk), bias, static_cast<unsigned short*>(y), y32, g, taps_d, taps_h, taps_w,
                        split, n_tiles, tiles_n, classes, xb, wb);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_dgrad_s2_halo(const void* dy, const void* wkt, void* dx, int N, int OD, int OH, int OW, int D, int H, int W,
+                                            int Cin, int Cout, void* hip_stream) {
+  if (!dy || !wkt || !dx) return TRANSOAR_CONVGEMM_ERR_NULL;
+  if (N <= 0 || OD <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cin > 32 || (Cin & 7) || (Cout != 16 && Cout != 32 && Cout != 48))
+    return TRANSOAR_CONVGEMM_ERR_DIM;
+  if ((D != 2 * OD && D != 2 * OD - 1) || (H != 2 * OH && H != 2 * OH - 1) || (W != 2 * OW && W != 2 * OW - 1)) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const long dy_bytes = static_cast<long>(N) * OD * OH * OW * Cout * 2;
+  if (dy_bytes >= 0x7ffffff0L) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const int td = (OD + kDs2TD - 1) / kDs2TD, th = (OH + kDs2TH - 1) / kDs2TH, tw = (OW + kDs2TW - 1) / kDs2TW;
+  const long n_tiles = static_cast<long>(N) * td * th * tw;
+  const unsigned blocks = static_cast<unsigned>(n_tiles < 768 ? n_tiles : 768);          // persistent: 3 workgroups per CU
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+#define TRANSOAR_DS2_LAUNCH(KS)                                                                                                     \
+  hipLaunchKernelGGL(conv3d_dgrad_s2_halo_kernel<KS>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned short*>(dy),       \
+                     static_cast<const unsigned short*>(wkt), static_cast<unsigned short*>(dx), N, OD, OH, OW, D, H, W, Cin, td, th, tw, \
+                     static_cast<unsigned>(dy_bytes))
+  if (Cout == 16) TRANSOAR_DS2_LAUNCH(1);
+  else if (Cout == 32) TRANSOAR_DS2_LAUNCH(2);
+  else TRANSOAR_DS2_LAUNCH(3);
+#undef TRANSOAR_DS2_LAUNCH
   return static_cast<int>(hipGetLastError());
 }
 
@@ -672,4 +697,4 @@ extern "C" int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cou
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_convgemm_abi_version(void) { return 1; }
+extern "C" int transoar_convgemm_abi_version(void) { return 2; }
