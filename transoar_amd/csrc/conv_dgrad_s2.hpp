@@ -120,25 +120,57 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_s2_halo_kernel(
   const int run_pieces = 2 * kDs2TW * row_bytes / 16;             // 16-byte pieces of one W-run of the dx tile
   const int out_pieces = 4 * kDs2TD * kDs2TH * run_pieces;
   const long n_tiles = static_cast<long>(N) * tiles_d * tiles_h * tiles_w;
-  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  // the 16-byte pieces of the dx tile this thread stores: the same for every tile (stage offset = 16 p)
+  constexpr int kStores = kDs2OutVox * 64 / 16 / 256;             // 8 at Cin = 32
+  unsigned out_off[kStores];                                      // < 2^31: checked by the host
+  int out_zz[kStores];
+#pragma unroll
+  for (int k = 0; k < kStores; ++k) {
+    const int p = tid + 256 * k;
+    const int run = p / run_pieces, pc = p - run * run_pieces;
+    const int zd = run / (2 * kDs2TH), zh = run - zd * (2 * kDs2TH);
+    out_off[k] = static_cast<unsigned>((zd * H + zh) * W * row_bytes + pc * 16);
+    out_zz[k] = p < out_pieces ? (zd | (zh << 8) | ((pc * 16 / row_bytes) << 16)) : 0xff;      // zd = 255: never stored
+  }
+  constexpr int kLoads = (kDs2HaloRows * kPieces + 255) / 256;
+  u32x4 pre[kLoads];
+  int jd0 = 0, jh0 = 0, jw0 = 0, b = 0;
+  // dy halo of tile t -> registers (rows beyond the map read as zeros); issued one tile ahead of its use
+  auto prefetch = [&](long t) {
     const int tw = static_cast<int>(t % tiles_w);
     long r = t / tiles_w;
     const int th = static_cast<int>(r % tiles_h);
     r /= tiles_h;
-    const int td = static_cast<int>(r % tiles_d), b = static_cast<int>(r / tiles_d);
-    const int jd0 = td * kDs2TD, jh0 = th * kDs2TH, jw0 = tw * kDs2TW;
-    // ---- dy halo -> LDS (rows beyond the map read as zeros)
-    for (int p = tid; p < kDs2HaloRows * kPieces; p += 256) {
+    const int td = static_cast<int>(r % tiles_d), bb = static_cast<int>(r / tiles_d);
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int p = tid + 256 * k;
       const int row = p / kPieces, pc = p - row * kPieces;
       const int hd = row / ((kDs2TH + 1) * (kDs2TW + 1)), rem = row - hd * ((kDs2TH + 1) * (kDs2TW + 1));
       const int hh = rem / (kDs2TW + 1), hw = rem - hh * (kDs2TW + 1);
-      const int jd = jd0 + hd, jh = jh0 + hh, jw = jw0 + hw;
-      const bool ok = jd < OD && jh < OH && jw < OW;
-      const unsigned off = static_cast<unsigned>(((b * OD + jd) * OH + jh) * OW + jw) * static_cast<unsigned>(32 * KS) + pc * 16;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? off : 0x80000000u, 0, 0);
-      *reinterpret_cast<u32x4*>(halo + row * kPitch + pc * 16) = v;
+      const int jd = td * kDs2TD + hd, jh = th * kDs2TH + hh, jw = tw * kDs2TW + hw;
+      const bool ok = p < kDs2HaloRows * kPieces && jd < OD && jh < OH && jw < OW;
+      const unsigned off = static_cast<unsigned>(((bb * OD + jd) * OH + jh) * OW + jw) * static_cast<unsigned>(32 * KS) + pc * 16;
+      pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? off : 0x80000000u, 0, 0);
+    }
+  };
+  if (blockIdx.x < n_tiles) prefetch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    {
+      const int tw = static_cast<int>(t % tiles_w);
+      long r = t / tiles_w;
+      const int th = static_cast<int>(r % tiles_h);
+      r /= tiles_h;
+      jd0 = static_cast<int>(r % tiles_d) * kDs2TD; jh0 = th * kDs2TH; jw0 = tw * kDs2TW; b = static_cast<int>(r / tiles_d);
+    }
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int p = tid + 256 * k;
+      const int row = p / kPieces, pc = p - row * kPieces;
+      if (p < kDs2HaloRows * kPieces) *reinterpret_cast<u32x4*>(halo + row * kPitch + pc * 16) = pre[k];
     }
     __syncthreads();
+    if (t + gridDim.x < n_tiles) prefetch(t + gridDim.x);       // in flight during the MFMA phase
     switch (wave) {
       case 0: ds2_compute<KS, 7, -1, -1>(a, halo, stage, cin, lane); break;
       case 1: ds2_compute<KS, 3, 4, 0>(a, halo, stage, cin, lane); break;
@@ -147,14 +179,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_s2_halo_kernel(
     }
     __syncthreads();
     // ---- dense dx tile -> global: W-runs of 16 voxels (2 Cin x 16 bytes, contiguous)
-    for (int p = tid; p < out_pieces; p += 256) {
-      const int run = p / run_pieces, pc = p - run * run_pieces;
-      const int zd = run / (2 * kDs2TH), zh = run - zd * (2 * kDs2TH);
-      const int xd = 2 * jd0 + zd, xh = 2 * jh0 + zh, xw0 = 2 * jw0;
-      const int vox = pc * 16 / row_bytes;                        // voxel of the run this piece belongs to
-      if (xd < D && xh < H && xw0 + vox < W) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + run * (2 * kDs2TW) * row_bytes + pc * 16);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(DX) + (((static_cast<long>(b) * D + xd) * H + xh) * W + xw0) * row_bytes + pc * 16) = v;
+    {
+      const int xd0 = 2 * jd0, xh0 = 2 * jh0, xw0 = 2 * jw0;
+      unsigned char* tile = reinterpret_cast<unsigned char*>(DX) + (((static_cast<long>(b) * D + xd0) * H + xh0) * W + xw0) * row_bytes;
+#pragma unroll
+      for (int k = 0; k < kStores; ++k) {
+        const int zd = out_zz[k] & 0xff, zh = (out_zz[k] >> 8) & 0xff, vox = out_zz[k] >> 16;
+        if (xd0 + zd < D && xh0 + zh < H && xw0 + vox < W)
+          *reinterpret_cast<u32x4*>(tile + out_off[k]) = *reinterpret_cast<const u32x4*>(stage + (tid + 256 * k) * 16);
       }
     }
     // no barrier here: the next tile's halo stores touch only `halo` (last read before the barrier above), and `stage`

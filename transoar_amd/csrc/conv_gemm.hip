@@ -626,10 +626,23 @@ extern "C" int transoar_conv3d_dgrad_s2_halo(const void* dy, const void* wkt, vo
     return TRANSOAR_CONVGEMM_ERR_DIM;
   if ((D != 2 * OD && D != 2 * OD - 1) || (H != 2 * OH && H != 2 * OH - 1) || (W != 2 * OW && W != 2 * OW - 1)) return TRANSOAR_CONVGEMM_ERR_DIM;
   const long dy_bytes = static_cast<long>(N) * OD * OH * OW * Cout * 2;
-  if (dy_bytes >= 0x7ffffff0L) return TRANSOAR_CONVGEMM_ERR_DIM;
+  if (dy_bytes >= 0x7ffffff0L || (4L * H + 8) * W * Cin * 2 >= 0x7ffffff0L) return TRANSOAR_CONVGEMM_ERR_DIM;     // 32-bit offsets inside a tile
   const int td = (OD + kDs2TD - 1) / kDs2TD, th = (OH + kDs2TH - 1) / kDs2TH, tw = (OW + kDs2TW - 1) / kDs2TW;
   const long n_tiles = static_cast<long>(N) * td * th * tw;
-  const unsigned blocks = static_cast<unsigned>(n_tiles < 768 ? n_tiles : 768);          // persistent: 3 workgroups per CU
+  // persistent: exactly one resident set of workgroups (a partial second set would run alone at the end)
+  static int resident[3] = {0, 0, 0};
+  const int ki = Cout / 16 - 1;
+  if (!resident[ki]) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const void* fn = ki == 0 ? reinterpret_cast<const void*>(conv3d_dgrad_s2_halo_kernel<1>)
+                   : ki == 1 ? reinterpret_cast<const void*>(conv3d_dgrad_s2_halo_kernel<2>) : reinterpret_cast<const void*>(conv3d_dgrad_s2_halo_kernel<3>);
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1)
+      return TRANSOAR_CONVGEMM_ERR_DIM;
+    resident[ki] = per_cu * prop.multiProcessorCount;
+  }
+  const unsigned blocks = static_cast<unsigned>(n_tiles < resident[ki] ? n_tiles : resident[ki]);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
 #define TRANSOAR_DS2_LAUNCH(KS)                                                                                                     \
   hipLaunchKernelGGL(conv3d_dgrad_s2_halo_kernel<KS>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned short*>(dy),       \
