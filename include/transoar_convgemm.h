@@ -80,6 +80,13 @@ int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw,
 /* nn.Conv3d's fp32 weight (Cout, Cin, 3,3,3) -> wk (27, Cout, Cin) bf16 and, if wkt != NULL, wkt (27, Cin, Cout) bf16 */
 int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cout, int Cin, void* hip_stream);
 
+/*
+ * The same for many layers in ONE launch.  table (device memory): n_layers records of five 64-bit words
+ * {w, wk, wkt (or 0), Cout | Cin << 32, first tile}, where a layer has ceil(Cout/32) * ceil(Cin/32) tiles numbered
+ * consecutively from its first tile; total_tiles = the sum (= the grid).  All fp32 weights contiguous (Cout, Cin, 27).
+ */
+int transoar_conv3d_pack_many(const void* table, int n_layers, long total_tiles, void* hip_stream);
+
 int transoar_convgemm_abi_version(void);
 
 #ifdef __cplusplus

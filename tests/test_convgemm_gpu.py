@@ -97,3 +97,30 @@ def test_filter_pack_kernel(co, ci):
     finally:
         del os.environ["TRANSOAR_CONV_PACK_HIP"]
     assert torch.equal(wk, G.pack_fwd(w)) and torch.equal(wkt, G.pack_dgrad(w))
+
+
+def test_pack_plan_packs_many_layers_in_one_launch():
+    """conv_gemm.PackPlan: one launch for the filter packs of several layers == the per-layer torch packs, and
+    Conv3dK3 uses them exactly as long as the weight version matches."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    from transoar_amd.conv3d import Conv3dK3
+    torch.manual_seed(3)
+    mods = [Conv3dK3(ci, co, 3, stride=s, padding=1, bias=False).cuda() for ci, co, s in [(24, 48, 2), (48, 48, 1), (96, 200, 2), (40, 56, 1)]]
+    plan = G.PackPlan(mods)
+    plan.run()
+    for m in mods:
+        wk, wkt = m._packs
+        assert m._packs_version == m.weight._version
+        assert torch.equal(wk, G.pack_fwd(m.weight.detach())) and torch.equal(wkt, G.pack_dgrad(m.weight.detach()))
+    m = mods[1]
+    x = torch.randn(1, 48, 4, 6, 8, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_plan = m(x)
+        with torch.no_grad():
+            m.weight.mul_(2.0)                    # version bump: the packs are stale and must not be used
+        assert m._packs_version != m.weight._version
+        y_new = m(x)
+    assert torch.allclose(y_new.float(), 2 * y_plan.float(), rtol=2e-2, atol=1e-3)
+    assert plan.valid()

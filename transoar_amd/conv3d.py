@@ -221,7 +221,7 @@ def c1_wgrad_supported(x, gy):
 
 class _Conv3dK3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride):
+    def forward(ctx, x, weight, bias, stride, packs=None):
         # one input channel: NDHWC == NCDHW; keep canonical strides so nothing downstream
         # (MIOpen's weight gradient) mistakes it for a channels-last problem
         xb = x.to(torch.bfloat16).contiguous() if x.shape[1] == 1 else _as_ndhwc(x)
@@ -244,7 +244,9 @@ class _Conv3dK3(torch.autograd.Function):
         elif _use_gemm(ci, weight.shape[0], stride):
             # 48 channels and up (and the strided 24 -> 48 layer): LDS-tiled implicit GEMM (csrc/conv_gemm.hip)
             # both filter packs in one pass over the fp32 weight when the backward will want the second one
-            if weight.requires_grad or x.requires_grad:
+            if packs is not None:
+                wk, wkt = packs                 # packed for this weight version by conv_gemm.PackPlan (one launch per step)
+            elif weight.requires_grad or x.requires_grad:
                 wk, wkt = _cg.pack_both(weight)
             else:
                 wk = _cg.pack_fwd(weight)
@@ -307,7 +309,7 @@ class _Conv3dK3(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g2 = gyb.permute(0, 2, 3, 4, 1).reshape(-1, gyb.shape[1])        # channels-last: a view, rows = voxels
             gb = _rows.colsum(g2) if _rows.colsum_usable(g2) else gyb.float().sum(dim=(0, 2, 3, 4))
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def _use_gemm(cin, cout, stride):
@@ -336,6 +338,10 @@ class Conv3dK3(nn.Conv3d):
     # and miopen_db/ holds find-db entries for the NDHWC keys of every layer of the flagship model (52.2 -> 51.4 ms
     # per step against converting to NCDHW first).  TRANSOAR_NDHWC_ALL=0: convert (the round-1 behaviour).
     ndhwc_everywhere = os.environ.get("TRANSOAR_NDHWC_ALL", "1") == "1"
+    _packs, _packs_version = None, -1          # filter packs of the current weight version (conv_gemm.PackPlan), if any
+
+    def uses_gemm(self):
+        return self.kernel_size == (3, 3, 3) and _use_gemm(self.in_channels, self.out_channels, self.stride[0])
 
     def forward(self, x):
         amp = torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_gpu_dtype() == torch.bfloat16
@@ -344,7 +350,8 @@ class Conv3dK3(nn.Conv3d):
             s = self.stride[0]
             voxels = xb.shape[0] * (xb.shape[2] // s) * (xb.shape[3] // s) * (xb.shape[4] // s)
             if voxels >= Conv3dK3.min_voxels:
-                return _Conv3dK3.apply(xb, self.weight, self.bias, s)
+                packs = self._packs if self._packs_version == self.weight._version else None
+                return _Conv3dK3.apply(xb, self.weight, self.bias, s, packs)
         # stock convolution (MIOpen on the GPU): NCDHW-contiguous input, see the note in backward
         if x.is_cuda and not Conv3dK3.ndhwc_everywhere:
             x = to_ncdhw(x)

@@ -34,6 +34,8 @@ def _load():
     lib.transoar_conv3d_dgrad_s2_halo.argtypes = [p, p, p] + [i] * 9 + [p]
     lib.transoar_conv3d_pack.restype = i
     lib.transoar_conv3d_pack.argtypes = [p, p, p, i, i, p]
+    lib.transoar_conv3d_pack_many.restype = i
+    lib.transoar_conv3d_pack_many.argtypes = [p, i, ctypes.c_long, p]
     lib.transoar_convgemm_abi_version.restype = i
     if lib.transoar_convgemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -95,6 +97,41 @@ def pack_both(weight):
     with torch.cuda.device(weight.device):
         _check(lib.transoar_conv3d_pack(weight.data_ptr(), wk.data_ptr(), wkt.data_ptr(), co, ci, _stream()), "transoar_conv3d_pack")
     return wk, wkt
+
+
+class PackPlan:
+    """Both filter packs of MANY convolution layers in one launch (transoar_conv3d_pack_many), into persistent buffers.
+    modules: objects with a contiguous fp32 `.weight` (Cout, Cin, 3,3,3); after run() each module carries
+    `_packs = (wk, wkt)` and `_packs_version = weight._version`, which conv3d.Conv3dK3 uses as long as the weight has not
+    been written since (an optimizer step bumps the version; a captured graph replays the pack kernel with the step)."""
+
+    def __init__(self, modules):
+        self.modules = list(modules)
+        assert self.modules
+        dev = self.modules[0].weight.device
+        self.buffers, rows, tile = [], [], 0
+        for m in self.modules:
+            w = m.weight
+            assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape[2:]) == (3, 3, 3) and w.device == dev
+            co, ci = w.shape[:2]
+            wk = torch.empty((27, co, ci), dtype=torch.bfloat16, device=dev)
+            wkt = torch.empty((27, ci, co), dtype=torch.bfloat16, device=dev)
+            self.buffers.append((wk, wkt))
+            rows.append([w.data_ptr(), wk.data_ptr(), wkt.data_ptr(), co | (ci << 32), tile])
+            tile += ((co + 31) // 32) * ((ci + 31) // 32)
+        self.total_tiles = tile
+        self.ptrs = [r[0] for r in rows]
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+
+    def valid(self):
+        return all(m.weight.data_ptr() == p for m, p in zip(self.modules, self.ptrs))
+
+    def run(self):
+        with torch.cuda.device(self.table.device):
+            _check(lib.transoar_conv3d_pack_many(self.table.data_ptr(), len(self.modules), self.total_tiles, _stream()),
+                   "transoar_conv3d_pack_many")
+        for m, packs in zip(self.modules, self.buffers):
+            m._packs, m._packs_version = packs, m.weight._version
 
 
 def _split_for(tiles, k_steps):

@@ -62,6 +62,21 @@ class TrainStep:
         self.num_classes = config["num_classes"]
         self.device_type = next(model.parameters()).device.type
 
+    def _prepack(self):
+        """Filter packs of every implicit-GEMM convolution for this step's weights in one launch (conv_gemm.PackPlan)
+        instead of two permute + cast copies per layer; part of the captured step."""
+        if os.environ.get("TRANSOAR_CONV_PREPACK", "1") == "0":
+            return
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or not plan.valid():
+            from .conv3d import Conv3dK3
+            from .conv_gemm import PackPlan
+            mods = [m for m in self.model.modules() if isinstance(m, Conv3dK3) and Conv3dK3.enabled and m.uses_gemm()
+                    and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+            plan = self._pack_plan = PackPlan(mods) if mods else False
+        if plan:
+            plan.run()
+
     def end_epoch(self):
         """Advance the learning-rate schedule (the reference steps it after every epoch, trainer.py:220).  The
         fused AdamW reads the group's lr on every step, so this is safe next to a captured graph."""
@@ -81,6 +96,8 @@ class TrainStep:
             counts = self.reducer.reduce_counts(counts)
             targets = DenseTargets(targets.boxes, targets.present, counts[0], counts[1])
         enabled = self.amp_dtype is not None and self.amp_dtype != torch.float32
+        if enabled and self.amp_dtype == torch.bfloat16 and data.is_cuda and torch.is_grad_enabled():
+            self._prepack()
         with torch.autocast(self.device_type, dtype=self.amp_dtype if enabled else torch.bfloat16, enabled=enabled):
             out = self.model(data)
             losses = self.criterion(out, targets, seg_targets, self.model._anchors)
