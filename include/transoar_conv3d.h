@@ -97,6 +97,13 @@ int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, 
  */
 int transoar_conv3d_c1_wgrad(const void* x, const void* dy, float* partial, int n_partial, int N, int D,
                              int H, int W, int Cout, void* hip_stream);
+/*
+ * The same with coalesced 16-byte loads (dy rows through LDS and the transposing LDS read, x rows staged three times,
+ * shifted by kw): Cout % 8 == 0, W % 64 == 0, W <= 256.  n_partial: about 4 workgroups per CU; each walks
+ * ceil(N*D*H / n_partial) consecutive W-rows.
+ */
+int transoar_conv3d_c1_wgrad_tr(const void* x, const void* dy, float* partial, int n_partial, int N, int D,
+                                int H, int W, int Cout, void* hip_stream);
 
 /*
  * bf16 layout change between channels-last (N, V, C) and channels-first

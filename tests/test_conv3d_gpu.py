@@ -24,6 +24,8 @@ CASES = [  # N, Cin, Cout, D, H, W, stride, bias
     # >= 2^16 voxels, stride 1, <= 24 -> <= 32 channels: the LDS halo-tile kernel, partial tiles on every axis
     (1, 24, 24, 18, 22, 200, 1, False), (1, 8, 32, 20, 30, 120, 1, True), (2, 16, 24, 17, 33, 136, 1, False),
     (1, 1, 24, 18, 30, 128, 1, False),
+    # Cin = 1, W % 64 == 0: the coalesced weight gradient (dy through the transposing LDS read, x rows staged per kw)
+    (2, 1, 24, 5, 7, 64, 1, False), (1, 1, 32, 4, 6, 256, 1, False), (2, 1, 8, 3, 5, 192, 1, False), (1, 1, 16, 6, 4, 256, 1, True),
 ]
 
 

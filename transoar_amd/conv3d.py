@@ -22,7 +22,7 @@ from . import conv_gemm as _cg
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_conv3d.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def _load():
@@ -38,6 +38,8 @@ def _load():
     lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 10 + [p]
     lib.transoar_conv3d_c1_wgrad.restype = i
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
+    lib.transoar_conv3d_c1_wgrad_tr.restype = i
+    lib.transoar_conv3d_c1_wgrad_tr.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_k3_forward_c1.restype = i
     lib.transoar_conv3d_k3_forward_c1.argtypes = [p, p, p, p] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
@@ -174,17 +176,20 @@ def conv3d_k3_wgrad(x, gy, stride):
 
 
 C1_WGRAD_PARTIALS = 3200
+C1_WGRAD_TR = os.environ.get("TRANSOAR_C1_WGRAD_TR", "1") != "0"
+C1_WGRAD_TR_PARTIALS = 1024         # persistent: 4 workgroups per CU
 
 
 def conv3d_c1_wgrad(x, gy):
     """x (N,1,D,H,W) bf16 contiguous, gy (N,Cout,D,H,W) bf16 NDHWC -> dW (Cout,1,3,3,3) fp32."""
     n, _, d, h, w = x.shape
     co = gy.shape[1]
-    n_part = min(C1_WGRAD_PARTIALS, max(1, (n * d * h + 3) // 4))
+    tr = C1_WGRAD_TR and co % 8 == 0 and w % 64 == 0 and w <= 256          # coalesced loads + transposing LDS reads
+    n_part = min(C1_WGRAD_TR_PARTIALS, n * d * h) if tr else min(C1_WGRAD_PARTIALS, max(1, (n * d * h + 3) // 4))
     partial = torch.empty((n_part, 32, 32), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib.transoar_conv3d_c1_wgrad(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), n_part, n, d, h, w, co,
-                                            _stream()), "transoar_conv3d_c1_wgrad")
+        fn = lib.transoar_conv3d_c1_wgrad_tr if tr else lib.transoar_conv3d_c1_wgrad
+        _check(fn(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), n_part, n, d, h, w, co, _stream()), "transoar_conv3d_c1_wgrad")
     return partial.sum(0)[:co, :27].reshape(co, 1, 3, 3, 3)
 
 

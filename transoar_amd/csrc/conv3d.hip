@@ -616,6 +616,124 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const unsigned short* __r
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same weight gradient (Cin == 1) with coalesced loads: conv3d_c1_wgrad above gathers both MFMA operands with
+// 2-byte loads (16 per lane and MFMA) and waits for them -- 0.76 ms on the flagship stem where the 630 MB of dy are
+// 0.15 ms of HBM time (profiles/r03_conv_pmc.txt: 181 K of 204 K wave cycles waiting).  Here a workgroup walks W-rows
+// (b, d, h) of W <= 256 voxels:
+//   dy row   -> LDS as it lies in memory ([voxel][Cout], 64-byte pitch, 16-byte loads one row ahead); the A fragment
+//               (cout x 16 voxels) is cut out with the transposing ds_read_b64_tr_b16 (4 rows x 64 bytes = all 64 banks)
+//   x rows   -> the 9 (kd, kh) neighbour rows, each stored THREE times, shifted by kw - 1 voxels (built in registers
+//               from the aligned 16-byte load + the neighbour lanes' edge elements): the B fragment of lane (tap, kg)
+//               is ONE aligned ds_read_b128 of copy kw; taps 27..31 read a row of zeros
+//   one v_mfma_f32_32x32x16_bf16 per 16 voxels and wave; the four waves take 64 voxels of the row each.
+// partial (gridDim.x, 32, 32) as above.
+// ---------------------------------------------------------------------------
+typedef short c1_s16x4 __attribute__((ext_vector_type(4)));
+typedef short c1_s16x8 __attribute__((ext_vector_type(8)));
+constexpr int kC1XP = 256 + 16;              // elements per staged x row
+
+template <int CO8>
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_tr(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                          float* __restrict__ partial, int N, int D, int H, int W, int Cout,
+                                                          long n_rows, int rows_per_wg, unsigned x_bytes, unsigned dy_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char dyt[256 * 64 + 512];       // + the transposing reads' over-reach; reused for the final sum
+  __shared__ __attribute__((aligned(16))) unsigned short xs[3][10][kC1XP];         // [kw][kd * 3 + kh | 9 = zeros][w]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x), 0, static_cast<int>(x_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dy), 0, static_cast<int>(dy_bytes), 0x00020000);
+  for (int i = tid; i < (256 * 64 + 512) / 4; i += 256) reinterpret_cast<unsigned*>(dyt)[i] = 0u;       // channels >= Cout stay zero
+  for (int i = tid; i < 3 * 10 * kC1XP / 2; i += 256) reinterpret_cast<unsigned*>(&xs[0][0][0])[i] = 0u;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // fragment addresses (constant over the rows)
+  const int t_row = 8 * kg + ((lane & 15) >> 2), t_ch = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const unsigned char* a_base = dyt + (64 * wave + t_row) * 64 + t_ch * 2;
+  const int tap = lane & 31;
+  const unsigned short* b_base = tap < 27 ? &xs[tap % 3][tap / 3][64 * wave + 8 * kg] : &xs[0][9][64 * wave + 8 * kg];
+  typedef __attribute__((address_space(3))) c1_s16x4 lds_s16x4;
+
+  const long row_beg = static_cast<long>(blockIdx.x) * rows_per_wg, row_end = min(n_rows, row_beg + rows_per_wg);
+  u32x4c pdy[CO8], px[2];
+  const int dy_pieces = W * CO8;                       // 16-byte pieces of a dy row, contiguous in memory
+  auto prefetch = [&](long row) {
+#pragma unroll
+    for (int k = 0; k < CO8; ++k) {
+      const int p = tid + 256 * k;
+      pdy[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, p < dy_pieces ? static_cast<unsigned>(row) * static_cast<unsigned>(dy_pieces * 16) + p * 16 : 0x80000000u, 0, 0);
+    }
+    const int h = static_cast<int>(row % H);
+    const long bd = row / H;
+    const int d = static_cast<int>(bd % D);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k, r = i >> 5, piece = i & 31;
+      const int id = d + r / 3 - 1, ih = h + r % 3 - 1;
+      const bool ok = r < 9 && piece * 8 < W && static_cast<unsigned>(id) < static_cast<unsigned>(D) && static_cast<unsigned>(ih) < static_cast<unsigned>(H);
+      px[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? static_cast<unsigned>(((bd - d + id) * H + ih) * W + piece * 8) * 2u : 0x80000000u, 0, 0);
+    }
+  };
+  if (row_beg < row_end) prefetch(row_beg);
+  __syncthreads();
+  for (long row = row_beg; row < row_end; ++row) {
+    // ---- registers -> LDS
+#pragma unroll
+    for (int k = 0; k < CO8; ++k) {
+      const int p = tid + 256 * k;
+      if (p < dy_pieces) *reinterpret_cast<u32x4c*>(dyt + (p / CO8) * 64 + (p % CO8) * 16) = pdy[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k, r = i >> 5, piece = i & 31;
+      const u32x4c v = px[k];
+      // edge elements of the neighbouring pieces of the same row (32 consecutive lanes); zeros beyond the row
+      unsigned left = __shfl_up(v[3], 1), right = __shfl_down(v[0], 1);
+      if (piece == 0) left = 0u;
+      if (piece * 8 + 8 >= W) right = 0u;
+      if (r < 9 && piece * 8 < W) {
+        u32x4c lo, hi;                                  // shifted by -1 / +1 voxel
+        lo[0] = __builtin_amdgcn_alignbit(v[0], left, 16); lo[1] = __builtin_amdgcn_alignbit(v[1], v[0], 16);
+        lo[2] = __builtin_amdgcn_alignbit(v[2], v[1], 16); lo[3] = __builtin_amdgcn_alignbit(v[3], v[2], 16);
+        hi[0] = __builtin_amdgcn_alignbit(v[1], v[0], 16); hi[1] = __builtin_amdgcn_alignbit(v[2], v[1], 16);
+        hi[2] = __builtin_amdgcn_alignbit(v[3], v[2], 16); hi[3] = __builtin_amdgcn_alignbit(right, v[3], 16);
+        *reinterpret_cast<u32x4c*>(&xs[0][r][piece * 8]) = lo;       // tap kw = 0 sees x[w - 1]
+        *reinterpret_cast<u32x4c*>(&xs[1][r][piece * 8]) = v;
+        *reinterpret_cast<u32x4c*>(&xs[2][r][piece * 8]) = hi;
+      }
+    }
+    __syncthreads();
+    if (row + 1 < row_end) prefetch(row + 1);           // in flight during the MFMAs
+    if (64 * wave < W) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const c1_s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a_base + ks * 16 * 64));
+        const c1_s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a_base + ks * 16 * 64 + 4 * 64));
+        const c1_s16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const c1_s16x8 b = *reinterpret_cast<const c1_s16x8*>(b_base + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // 4 waves -> one tile: D[row = cout (r & 3) + 8 (r >> 2) + 4 kg][col = tap]
+  float* red = reinterpret_cast<float*>(dyt);            // [wave][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + static_cast<long>(blockIdx.x) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const float v = red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane];
+      out[co * 32 + tap] = (co < Cout && tap < 27) ? v : 0.f;
+    }
+  }
+}
+
 #include "conv3d_wgrad_lds.hpp"
 
 // ---------------------------------------------------------------------------
@@ -810,6 +928,29 @@ extern "C" int transoar_conv3d_c1_wgrad(const void* x, const void* dy, float* pa
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_conv3d_c1_wgrad_tr(const void* x, const void* dy, float* partial, int n_partial, int N, int D, int H,
+                                           int W, int Cout, void* hip_stream) {
+  if (!x || !dy || !partial) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || n_partial <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (Cout > 32 || (Cout & 7) || (W & 63) || W > 256) return TRANSOAR_CONV_ERR_CHANNELS;
+  const long n_rows = static_cast<long>(N) * D * H;
+  const long xb = n_rows * W * 2, dyb = n_rows * W * Cout * 2;
+  if (dyb >= 0x7ffffff0L) return TRANSOAR_CONV_ERR_DIM;
+  const int rows_per_wg = static_cast<int>((n_rows + n_partial - 1) / n_partial);
+#define TRANSOAR_C1TR(CO8)                                                                                                          \
+  hipLaunchKernelGGL(conv3d_c1_wgrad_tr<CO8>, dim3(static_cast<unsigned>(n_partial)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), \
+                     static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(dy), partial, N, D, H, W, Cout, n_rows,   \
+                     rows_per_wg, static_cast<unsigned>(xb), static_cast<unsigned>(dyb))
+  switch (Cout / 8) {
+    case 1: TRANSOAR_C1TR(1); break;
+    case 2: TRANSOAR_C1TR(2); break;
+    case 3: TRANSOAR_C1TR(3); break;
+    default: TRANSOAR_C1TR(4); break;
+  }
+#undef TRANSOAR_C1TR
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, int D, int H, int W,
                                           int Cout, void* hip_stream) {
   if (!x || !w || !y) return TRANSOAR_CONV_ERR_NULL;
@@ -838,4 +979,4 @@ extern "C" int transoar_layout_bf16(const void* in, void* out, int N, long V, in
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_conv3d_abi_version(void) { return 4; }
+extern "C" int transoar_conv3d_abi_version(void) { return 5; }
