@@ -87,6 +87,13 @@ int transoar_conv3d_c1_forward(const void* x, const float* w, void* y, int N, in
 int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float* partial, int n_wg, int N, int D,
                                  int H, int W, int Cin, int Cout, int ci0, int ci_n, int co0, int co_n,
                                  void* hip_stream);
+/*
+ * Second version of the same (same arguments, same partial layout): tiles staged as they lie in memory and transposed
+ * by the LDS read (ds_read_b64_tr_b16), four waves per workgroup sharing the 27 taps 7/7/7/6.  n_wg: 3 per CU.
+ */
+int transoar_conv3d_k3_wgrad_tr(const void* x, const void* dy, float* partial, int n_wg, int N, int D,
+                                 int H, int W, int Cin, int Cout, int ci0, int ci_n, int co0, int co_n,
+                                 void* hip_stream);
 
 /*
  * Weight gradient of the Cin == 1 first layer (stride 1, pad 1):

@@ -36,6 +36,8 @@ def _load():
     lib.transoar_conv3d_k3_wgrad.argtypes = [p, p, p] + [i] * 10 + [p]
     lib.transoar_conv3d_k3_wgrad_lds.restype = i
     lib.transoar_conv3d_k3_wgrad_lds.argtypes = [p, p, p, i] + [i] * 10 + [p]
+    lib.transoar_conv3d_k3_wgrad_tr.restype = i
+    lib.transoar_conv3d_k3_wgrad_tr.argtypes = [p, p, p, i] + [i] * 10 + [p]
     lib.transoar_conv3d_c1_wgrad.restype = i
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_wgrad_tr.restype = i
@@ -194,6 +196,8 @@ def conv3d_c1_wgrad(x, gy):
 
 
 LDS_WGRAD_GROUPS = 512
+LDS_WGRAD_TR = os.environ.get("TRANSOAR_WGRAD_TR", "1") != "0"      # second version: transposing LDS reads, 4 waves (conv3d_wgrad_tr.hpp)
+LDS_WGRAD_TR_GROUPS = 512                                            # 2 workgroups per CU (202 VGPRs), 2 waves per SIMD
 
 
 def conv3d_k3_wgrad_lds(x, gy):
@@ -205,10 +209,11 @@ def conv3d_k3_wgrad_lds(x, gy):
     for co0 in range(0, co, 32):
         for ci0 in range(0, ci, 32):
             co_n, ci_n = min(32, co - co0), min(32, ci - ci0)
-            partial = torch.empty((LDS_WGRAD_GROUPS, 27, 32, 32), dtype=torch.float32, device=x.device)
+            groups = LDS_WGRAD_TR_GROUPS if LDS_WGRAD_TR else LDS_WGRAD_GROUPS
+            fn = lib.transoar_conv3d_k3_wgrad_tr if LDS_WGRAD_TR else lib.transoar_conv3d_k3_wgrad_lds
+            partial = torch.empty((groups, 27, 32, 32), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
-                _check(lib.transoar_conv3d_k3_wgrad_lds(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), LDS_WGRAD_GROUPS,
-                                                        n, d, h, w, ci, co, ci0, ci_n, co0, co_n, _stream()),
+                _check(fn(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), groups, n, d, h, w, ci, co, ci0, ci_n, co0, co_n, _stream()),
                        "transoar_conv3d_k3_wgrad_lds")
             dw[co0:co0 + co_n, ci0:ci0 + ci_n] = partial.sum(0)[:, :co_n, :ci_n].permute(1, 2, 0)
     return dw.view(co, ci, 3, 3, 3)

@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_tr(const unsigned short* 
 }
 
 #include "conv3d_wgrad_lds.hpp"
+#include "conv3d_wgrad_tr.hpp"
 
 // ---------------------------------------------------------------------------
 // layout changes between channels-last (N, V, C) and channels-first (N, C, V),
@@ -912,6 +913,38 @@ extern "C" int transoar_conv3d_k3_wgrad_lds(const void* x, const void* dy, float
   TRANSOAR_WG_CASE(3, 1) TRANSOAR_WG_CASE(3, 2) TRANSOAR_WG_CASE(3, 3) TRANSOAR_WG_CASE(3, 4)
   TRANSOAR_WG_CASE(4, 1) TRANSOAR_WG_CASE(4, 2) TRANSOAR_WG_CASE(4, 3) TRANSOAR_WG_CASE(4, 4)
 #undef TRANSOAR_WG_CASE
+  return TRANSOAR_CONV_ERR_CHANNELS;
+}
+
+extern "C" int transoar_conv3d_k3_wgrad_tr(const void* x, const void* dy, float* partial, int n_wg, int N, int D, int H,
+                                           int W, int Cin, int Cout, int ci0, int ci_n, int co0, int co_n,
+                                           void* hip_stream) {
+  if (!x || !dy || !partial) return TRANSOAR_CONV_ERR_NULL;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_wg <= 0) return TRANSOAR_CONV_ERR_DIM;
+  if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 7) || (W & 63)) return TRANSOAR_CONV_ERR_CHANNELS;
+  if (ci_n <= 0 || co_n <= 0 || ci_n > 32 || co_n > 32 || (ci_n & 7) || (co_n & 7) || (ci0 & 7) || (co0 & 7) ||
+      ci0 < 0 || co0 < 0 || ci0 + ci_n > Cin || co0 + co_n > Cout)
+    return TRANSOAR_CONV_ERR_CHANNELS;
+  // tasks = (h chunk, segment, (b, d) slice): at least 4 per workgroup, chunks of >= 8 rows
+  const long columns = static_cast<long>(N) * D * (W / 64);
+  int h_chunks = 1;
+  while (columns * h_chunks < 4L * n_wg && (H + h_chunks) / (h_chunks + 1) >= 8) ++h_chunks;
+  const int h_chunk = (H + h_chunks - 1) / h_chunks;
+  h_chunks = (H + h_chunk - 1) / h_chunk;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  auto xs = static_cast<const unsigned short*>(x);
+  auto ds = static_cast<const unsigned short*>(dy);
+#define TRANSOAR_WT_CASE(CI, CO)                                                                         \
+  if (ci_n == 8 * CI && co_n == 8 * CO) {                                                                \
+    hipLaunchKernelGGL((conv3d_k3_wgrad_tr<CI, CO>), dim3(static_cast<unsigned>(n_wg)), dim3(kWtThreads), 0, st, xs, ds, \
+                       partial, N, D, H, W, h_chunks, h_chunk, Cin, ci0, Cout, co0);                  \
+    return static_cast<int>(hipGetLastError());                                                          \
+  }
+  TRANSOAR_WT_CASE(1, 1) TRANSOAR_WT_CASE(1, 2) TRANSOAR_WT_CASE(1, 3) TRANSOAR_WT_CASE(1, 4)
+  TRANSOAR_WT_CASE(2, 1) TRANSOAR_WT_CASE(2, 2) TRANSOAR_WT_CASE(2, 3) TRANSOAR_WT_CASE(2, 4)
+  TRANSOAR_WT_CASE(3, 1) TRANSOAR_WT_CASE(3, 2) TRANSOAR_WT_CASE(3, 3) TRANSOAR_WT_CASE(3, 4)
+  TRANSOAR_WT_CASE(4, 1) TRANSOAR_WT_CASE(4, 2) TRANSOAR_WT_CASE(4, 3) TRANSOAR_WT_CASE(4, 4)
+#undef TRANSOAR_WT_CASE
   return TRANSOAR_CONV_ERR_CHANNELS;
 }
 
