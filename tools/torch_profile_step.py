@@ -33,6 +33,12 @@ with open(os.path.join(ROOT, "gpurun_out", "step_ops.txt"), "w") as f:
     f.write(prof.key_averages(group_by_input_shape=True).table(
         sort_by="self_cuda_time_total", row_limit=80, max_name_column_width=48, max_shapes_column_width=70))
 
+# every (op, input shapes) with its own GPU time, no row limit: gpurun_out/step_ops_all.tsv
+with open(os.path.join(ROOT, "gpurun_out", "step_ops_all.tsv"), "w") as f:
+    for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
+        if e.self_device_time_total > 0:
+            f.write("%s\t%d\t%.1f\t%s\n" % (e.key, e.count, e.self_device_time_total, str(e.input_shapes)[:200]))
+
 # kernels per source line of this package (innermost transoar_amd frame of the launching op)
 by_line = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
