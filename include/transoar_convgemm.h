@@ -77,6 +77,16 @@ int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw,
                           int Cout, int MD, int MH, int MW, int src_stride,
                           unsigned taps_d, unsigned taps_h, unsigned taps_w, int chunks, int taps_out, void* hip_stream);
 
+/*
+ * The same weight gradient (all 27 taps, taps_out = 27, forward tap lists) for layers with Cin, Cout <= 64 and
+ * MW % 64 == 0 (the 24 -> 48 / stride 2 and 48 -> 48 layers of stage 1): a workgroup owns one filter plane kd and one
+ * 32 x 32 channel tile and keeps the three x rows of its plane in an LDS ring, so that x and dy pass through L2 a few
+ * times instead of 27.  chunks = workgroups per (kd, co tile, ci tile) variant (the grid is chunks x variants; about 500
+ * workgroups in total); part: transoar_conv3d_wgrad_part_floats(Cin, Cout, chunks, 27) floats.
+ */
+int transoar_conv3d_wgrad_ring(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
+                               int Cout, int MD, int MH, int MW, int src_stride, int chunks, void* hip_stream);
+
 /* nn.Conv3d's fp32 weight (Cout, Cin, 3,3,3) -> wk (27, Cout, Cin) bf16 and, if wkt != NULL, wkt (27, Cin, Cout) bf16 */
 int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cout, int Cin, void* hip_stream);
 

@@ -48,7 +48,8 @@ def test_conv_gemm_forward_dgrad_wgrad(case, split):
 
 
 @pytest.mark.parametrize("case", [(1, 24, 48, 8, 8, 16), (2, 24, 48, 7, 9, 15), (1, 8, 16, 5, 6, 18), (1, 32, 32, 9, 8, 17),
-                                  (2, 16, 48, 12, 10, 20), (1, 24, 48, 20, 24, 48)])
+                                  (2, 16, 48, 12, 10, 20), (1, 24, 48, 20, 24, 48),
+                                  (1, 24, 48, 260, 8, 16)])          # D > 255: the piece table's 'no piece' marker must not alias a row
 def test_stride2_dgrad_halo_kernel(case):
     """transoar_conv3d_dgrad_s2_halo (few input channels: all eight parity classes of a dx tile in one workgroup) against
     torch's fp32 data gradient and against the general parity-class launch; odd sizes: D = 2 OD - 1, partial tiles."""
@@ -69,6 +70,29 @@ def test_stride2_dgrad_halo_kernel(case):
     assert gx.is_contiguous(memory_format=torch.channels_last_3d)
     assert relerr(gx, xr.grad) <= 2.0 ** -7
     assert relerr(gx, general) <= 2.0 ** -7
+
+
+@pytest.mark.parametrize("case", [(1, 24, 48, 12, 20, 256, 2), (2, 48, 48, 5, 9, 128, 1), (1, 24, 24, 6, 18, 64, 1), (1, 56, 40, 7, 11, 127, 2),
+                                  (1, 64, 64, 4, 17, 64, 1), (1, 8, 16, 9, 40, 255, 2)])
+def test_weight_gradient_ring_kernel(case):
+    """transoar_conv3d_wgrad_ring (one filter plane + one 32 x 32 channel tile per workgroup, x rows in an LDS ring, K split
+    over the waves) against torch's fp32 weight gradient and the general voxel-major kernel; odd source sizes, 1-2 channel
+    tiles, stride 1 and 2, tasks that start in the middle of a column."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from transoar_amd import conv_gemm as G
+    n, ci, co, d, h, w, s = case
+    torch.manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, d, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    wr = torch.zeros(co, ci, 3, 3, 3, device="cuda", requires_grad=True)
+    yr = F.conv3d(x.float(), wr, None, stride=s, padding=1)
+    assert yr.shape[-1] % 64 == 0
+    g = torch.randn_like(yr).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    yr.backward(g.float())
+    got = G.conv_wgrad_ring(x, g, s)
+    assert relerr(got, wr.grad) <= 2e-3
+    general = G._wgrad(x, g, (n, d, h, w, ci, co) + tuple(yr.shape[2:]) + (s,), (G.TAPS_FWD,) * 3, 27, (co, ci, 3, 3, 3))
+    assert relerr(got, general) <= 2e-3
 
 
 @pytest.mark.parametrize("t,k,nn_", [(1000, 384, 384), (4097, 384, 1024), (333, 1024, 384), (5000, 48, 64)])

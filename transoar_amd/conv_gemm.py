@@ -13,7 +13,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_convgemm.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 CL3D = torch.channels_last_3d
 
 
@@ -28,6 +28,8 @@ def _load():
     lib.transoar_conv3d_finish.argtypes = [p, p, p, ctypes.c_long, i, i, p]
     lib.transoar_conv3d_wgrad.restype = i
     lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
+    lib.transoar_conv3d_wgrad_ring.restype = i
+    lib.transoar_conv3d_wgrad_ring.argtypes = [p, p, p, p] + [i] * 11 + [p]
     lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
     lib.transoar_conv3d_wgrad_part_floats.argtypes = [i, i, i, i]
     lib.transoar_conv3d_dgrad_s2_halo.restype = i
@@ -217,10 +219,35 @@ def _wgrad(x2, gy2, geom, taps, taps_out, out_shape):
     return dw
 
 
+WGRAD_RING = os.environ.get("TRANSOAR_WGRAD_RING", "1") != "0"
+WGRAD_RING_BLOCKS = 504          # workgroups of a ring launch: a multiple of 8 (XCDs) and of 3, 6, 12 (variants), 2 per CU
+
+
+def wgrad_ring_supported(ci, co, ow, rows):
+    """The LDS-ring weight gradient (conv_wgrad_ring.hpp): up to 64 channels on either side, W-rows of dy in 64-voxel
+    units, enough voxels to keep ~500 persistent workgroups busy."""
+    return WGRAD_RING and ci <= 64 and co <= 64 and ci % 8 == 0 and co % 8 == 0 and ow % 64 == 0 and rows >= (1 << 18)
+
+
+def conv_wgrad_ring(x, gy, stride):
+    n, ci, d, h, w = x.shape
+    co, od, oh, ow = gy.shape[1:]
+    nv = 3 * ((co + 31) // 32) * ((ci + 31) // 32)
+    chunks = max(1, WGRAD_RING_BLOCKS // nv)
+    part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks, 27), dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_wgrad_ring(gy.data_ptr(), x.data_ptr(), part.data_ptr(), dw.data_ptr(), n, d, h, w, ci, co, od, oh, ow,
+                                              stride, chunks, _stream()), "transoar_conv3d_wgrad_ring")
+    return dw
+
+
 def conv_wgrad(x, gy, stride):
     """x (N, Cin, D, H, W), gy (N, Cout, Do, Ho, Wo) NDHWC bf16 -> dW (Cout, Cin, 3, 3, 3) fp32."""
     n, ci, d, h, w = x.shape
     co, od, oh, ow = gy.shape[1:]
+    if wgrad_ring_supported(ci, co, ow, n * od * oh * ow):
+        return conv_wgrad_ring(x, gy, stride)
     return _wgrad(x, gy, (n, d, h, w, ci, co, od, oh, ow, stride), (TAPS_FWD,) * 3, 27, (co, ci, 3, 3, 3))
 
 

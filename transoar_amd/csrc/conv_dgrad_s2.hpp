@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_s2_halo_kernel(
     const int run = p / run_pieces, pc = p - run * run_pieces;
     const int zd = run / (2 * kDs2TH), zh = run - zd * (2 * kDs2TH);
     out_off[k] = static_cast<unsigned>((zd * H + zh) * W * row_bytes + pc * 16);
-    out_zz[k] = p < out_pieces ? (zd | (zh << 8) | ((pc * 16 / row_bytes) << 16)) : 0xff;      // zd = 255: never stored
+    out_zz[k] = p < out_pieces ? (zd | (zh << 8) | ((pc * 16 / row_bytes) << 16)) : -1;        // -1: no piece (Cin < 32)
   }
   constexpr int kLoads = (kDs2HaloRows * kPieces + 255) / 256;
   u32x4 pre[kLoads];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_dgrad_s2_halo_kernel(
 #pragma unroll
       for (int k = 0; k < kStores; ++k) {
         const int zd = out_zz[k] & 0xff, zh = (out_zz[k] >> 8) & 0xff, vox = out_zz[k] >> 16;
-        if (xd0 + zd < D && xh0 + zh < H && xw0 + vox < W)
+        if (out_zz[k] >= 0 && xd0 + zd < D && xh0 + zh < H && xw0 + vox < W)
           *reinterpret_cast<u32x4*>(tile + out_off[k]) = *reinterpret_cast<const u32x4*>(stage + (tid + 256 * k) * 16);
       }
     }

@@ -598,6 +598,7 @@ __global__ __launch_bounds__(256) void conv3d_pack_many_kernel(const PackEntry* 
 }
 
 #include "conv_dgrad_s2.hpp"
+#include "conv_wgrad_ring.hpp"
 
 int check_geom(const ConvGeom& g) {
   if (g.N <= 0 || g.SD <= 0 || g.SH <= 0 || g.SW <= 0 || g.MD <= 0 || g.MH <= 0 || g.MW <= 0 || g.OD <= 0 || g.OH <= 0 || g.OW <= 0 ||
@@ -736,6 +737,35 @@ extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part,
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_conv3d_wgrad_ring(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
+                                          int Cout, int MD, int MH, int MW, int src_stride, int chunks, void* hip_stream) {
+  if (!dy || !x || !part || !dw) return TRANSOAR_CONVGEMM_ERR_NULL;
+  if (N <= 0 || SD <= 0 || SH <= 0 || SW <= 0 || MD <= 0 || MH <= 0 || MW <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout & 7) ||
+      Cin > 64 || Cout > 64 || (MW & 63) || chunks < 1 || (src_stride != 1 && src_stride != 2))
+    return TRANSOAR_CONVGEMM_ERR_DIM;
+  if (MD != (SD - 1) / src_stride + 1 || MH != (SH - 1) / src_stride + 1 || MW != (SW - 1) / src_stride + 1) return TRANSOAR_CONVGEMM_ERR_DIM;
+  const int tiles_co = (Cout + 31) / 32, tiles_ci = (Cin + 31) / 32, nv = 3 * tiles_co * tiles_ci;
+  // tasks = (h chunk, W segment, (b, jd) slice): at least 4 per workgroup of a variant, chunks of >= 8 rows
+  const long columns = static_cast<long>(N) * MD * (MW / 64);
+  int h_chunks = 1;
+  while (columns * h_chunks < 4L * chunks && (MH + h_chunks) / (h_chunks + 1) >= 8) ++h_chunks;
+  const int h_chunk = (MH + h_chunks - 1) / h_chunks;
+  h_chunks = (MH + h_chunk - 1) / h_chunk;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(static_cast<unsigned>(chunks * nv));
+  auto dys = static_cast<const unsigned short*>(dy);
+  auto xs = static_cast<const unsigned short*>(x);
+  if (src_stride == 1)
+    hipLaunchKernelGGL(conv3d_wgrad_ring_kernel<1>, grid, dim3(256), 0, st, dys, xs, part, N, SD, SH, SW, MD, MH, MW, Cin, Cout, tiles_co, tiles_ci,
+                       h_chunks, h_chunk);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_ring_kernel<2>, grid, dim3(256), 0, st, dys, xs, part, N, SD, SH, SW, MD, MH, MW, Cin, Cout, tiles_co, tiles_ci,
+                       h_chunks, h_chunk);
+  const long coci = static_cast<long>(Cout) * Cin;
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((coci + 31) / 32)), dim3(256), 0, st, part, dw, chunks, 27, coci);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_conv3d_pack(const float* w, void* wk, void* wkt, int Cout, int Cin, void* hip_stream) {
   if (!w || !wk) return TRANSOAR_CONVGEMM_ERR_NULL;
   if (Cout <= 0 || Cin <= 0) return TRANSOAR_CONVGEMM_ERR_DIM;
@@ -753,4 +783,4 @@ extern "C" int transoar_conv3d_pack_many(const void* table, int n_layers, long t
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_convgemm_abi_version(void) { return 2; }
+extern "C" int transoar_convgemm_abi_version(void) { return 3; }
