@@ -78,11 +78,11 @@ int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw,
                           unsigned taps_d, unsigned taps_h, unsigned taps_w, int chunks, int taps_out, void* hip_stream);
 
 /*
- * The same weight gradient (all 27 taps, taps_out = 27, forward tap lists) for layers with Cin, Cout <= 64 and
- * MW % 64 == 0 (the 24 -> 48 / stride 2 and 48 -> 48 layers of stage 1): a workgroup owns one filter plane kd and one
- * 32 x 32 channel tile and keeps the three x rows of its plane in an LDS ring, so that x and dy pass through L2 a few
- * times instead of 27.  chunks = workgroups per (kd, co tile, ci tile) variant (the grid is chunks x variants; about 500
- * workgroups in total); part: transoar_conv3d_wgrad_part_floats(Cin, Cout, chunks, 27) floats.
+ * The same weight gradient (all 27 taps, taps_out = 27, forward tap lists) for layers with Cin, Cout <= 64, more than 32
+ * channels on at least one side and MW % 64 == 0 (the 24 -> 48 / stride 2 and 48 -> 48 layers of stage 1): a workgroup
+ * owns one filter plane kd and keeps the three x rows of its plane in an LDS ring, so that x and dy are fetched 3 times
+ * instead of 27.  chunks = workgroups per plane (the grid is 3 x chunks: about one workgroup of 512 threads per CU);
+ * part: transoar_conv3d_wgrad_part_floats(Cin, Cout, chunks, 27) floats.
  */
 int transoar_conv3d_wgrad_ring(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
                                int Cout, int MD, int MH, int MW, int src_stride, int chunks, void* hip_stream);

@@ -155,10 +155,11 @@ def test_convgemm_and_fused_gather_argument_errors():
     assert h(p16, p16, p16, 1, 4, 4, 8, 8, 8, 14, 24, 48, None) == -2        # W = 2 OW or 2 OW - 1
     rg = cg.transoar_conv3d_wgrad_ring
     rg.argtypes = [p] * 4 + [i] * 11 + [p]
-    assert rg(p16, p16, None, p16, 1, 4, 4, 64, 16, 16, 4, 4, 64, 1, 8, None) == -1
+    assert rg(p16, p16, None, p16, 1, 4, 4, 64, 48, 16, 4, 4, 64, 1, 8, None) == -1
     assert rg(p16, p16, p16, p16, 1, 4, 4, 64, 96, 16, 4, 4, 64, 1, 8, None) == -2      # Cin <= 64
-    assert rg(p16, p16, p16, p16, 1, 4, 4, 48, 16, 16, 4, 4, 48, 1, 8, None) == -2      # MW % 64
-    assert rg(p16, p16, p16, p16, 1, 4, 4, 128, 16, 16, 4, 4, 64, 1, 8, None) == -2     # MW = (SW - 1) / stride + 1
+    assert rg(p16, p16, p16, p16, 1, 4, 4, 48, 48, 16, 4, 4, 48, 1, 8, None) == -2      # MW % 64
+    assert rg(p16, p16, p16, p16, 1, 4, 4, 64, 16, 16, 4, 4, 64, 1, 8, None) == -2      # <= 32 x 32 channels: not this kernel
+    assert rg(p16, p16, p16, p16, 1, 4, 4, 128, 48, 16, 4, 4, 64, 1, 8, None) == -2     # MW = (SW - 1) / stride + 1
     cg.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
     assert cg.transoar_conv3d_wgrad_part_floats(96, 96, 10, 27) == 27 * 96 * 96 * 10
 

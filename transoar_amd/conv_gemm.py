@@ -220,20 +220,20 @@ def _wgrad(x2, gy2, geom, taps, taps_out, out_shape):
 
 
 WGRAD_RING = os.environ.get("TRANSOAR_WGRAD_RING", "1") != "0"
-WGRAD_RING_BLOCKS = 504          # workgroups of a ring launch: a multiple of 8 (XCDs) and of 3, 6, 12 (variants), 2 per CU
+WGRAD_RING_CHUNKS = 85           # workgroups per filter plane of a ring launch: 3 x 85 = one 512-thread workgroup per CU
 
 
 def wgrad_ring_supported(ci, co, ow, rows):
-    """The LDS-ring weight gradient (conv_wgrad_ring.hpp): up to 64 channels on either side, W-rows of dy in 64-voxel
-    units, enough voxels to keep ~500 persistent workgroups busy."""
-    return WGRAD_RING and ci <= 64 and co <= 64 and ci % 8 == 0 and co % 8 == 0 and ow % 64 == 0 and rows >= (1 << 18)
+    """The LDS-ring weight gradient (conv_wgrad_ring.hpp): up to 64 channels on either side and more than 32 on at least
+    one, W-rows of dy in 64-voxel units, enough voxels to keep one persistent workgroup per CU busy."""
+    return (WGRAD_RING and ci <= 64 and co <= 64 and max(ci, co) > 32 and ci % 8 == 0 and co % 8 == 0 and ow % 64 == 0
+            and rows >= (1 << 18))
 
 
-def conv_wgrad_ring(x, gy, stride):
+def conv_wgrad_ring(x, gy, stride, chunks=None):
     n, ci, d, h, w = x.shape
     co, od, oh, ow = gy.shape[1:]
-    nv = 3 * ((co + 31) // 32) * ((ci + 31) // 32)
-    chunks = max(1, WGRAD_RING_BLOCKS // nv)
+    chunks = chunks or WGRAD_RING_CHUNKS
     part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(ci, co, chunks, 27), dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):

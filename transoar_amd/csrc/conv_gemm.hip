@@ -744,23 +744,24 @@ extern "C" int transoar_conv3d_wgrad_ring(const void* dy, const void* x, float* 
       Cin > 64 || Cout > 64 || (MW & 63) || chunks < 1 || (src_stride != 1 && src_stride != 2))
     return TRANSOAR_CONVGEMM_ERR_DIM;
   if (MD != (SD - 1) / src_stride + 1 || MH != (SH - 1) / src_stride + 1 || MW != (SW - 1) / src_stride + 1) return TRANSOAR_CONVGEMM_ERR_DIM;
-  const int tiles_co = (Cout + 31) / 32, tiles_ci = (Cin + 31) / 32, nv = 3 * tiles_co * tiles_ci;
-  // tasks = (h chunk, W segment, (b, jd) slice): at least 4 per workgroup of a variant, chunks of >= 8 rows
+  const int tiles_co = (Cout + 31) / 32, tiles_ci = (Cin + 31) / 32;
+  if (tiles_co * tiles_ci < 2) return TRANSOAR_CONVGEMM_ERR_DIM;        // 8 waves = 2 or 4 channel-tile pairs x a K split (<= 32 x 32: conv3d.hip's kernel)
+  // tasks = (h chunk, W segment, (b, jd) slice): at least 4 per workgroup of a plane, chunks of >= 8 rows
   const long columns = static_cast<long>(N) * MD * (MW / 64);
   int h_chunks = 1;
   while (columns * h_chunks < 4L * chunks && (MH + h_chunks) / (h_chunks + 1) >= 8) ++h_chunks;
   const int h_chunk = (MH + h_chunks - 1) / h_chunks;
   h_chunks = (MH + h_chunk - 1) / h_chunk;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const dim3 grid(static_cast<unsigned>(chunks * nv));
+  const dim3 grid(static_cast<unsigned>(chunks * 3));
   auto dys = static_cast<const unsigned short*>(dy);
   auto xs = static_cast<const unsigned short*>(x);
-  if (src_stride == 1)
-    hipLaunchKernelGGL(conv3d_wgrad_ring_kernel<1>, grid, dim3(256), 0, st, dys, xs, part, N, SD, SH, SW, MD, MH, MW, Cin, Cout, tiles_co, tiles_ci,
-                       h_chunks, h_chunk);
-  else
-    hipLaunchKernelGGL(conv3d_wgrad_ring_kernel<2>, grid, dim3(256), 0, st, dys, xs, part, N, SD, SH, SW, MD, MH, MW, Cin, Cout, tiles_co, tiles_ci,
-                       h_chunks, h_chunk);
+#define TRANSOAR_RING_LAUNCH(S_, CIT_)                                                                                                    \
+  hipLaunchKernelGGL((conv3d_wgrad_ring_kernel<S_, CIT_>), grid, dim3(512), 0, st, dys, xs, part, N, SD, SH, SW, MD, MH, MW, Cin, Cout, tiles_co, \
+                     tiles_ci, h_chunks, h_chunk)
+  if (src_stride == 1) { if (tiles_ci == 1) TRANSOAR_RING_LAUNCH(1, 1); else TRANSOAR_RING_LAUNCH(1, 2); }
+  else { if (tiles_ci == 1) TRANSOAR_RING_LAUNCH(2, 1); else TRANSOAR_RING_LAUNCH(2, 2); }
+#undef TRANSOAR_RING_LAUNCH
   const long coci = static_cast<long>(Cout) * Cin;
   hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((coci + 31) / 32)), dim3(256), 0, st, part, dw, chunks, 27, coci);
   return static_cast<int>(hipGetLastError());
