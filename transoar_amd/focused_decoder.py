@@ -30,7 +30,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import rows
+from . import rows, shadow
 from .position_encoding import is_constant
 from .token_linear import token_linear
 
@@ -193,18 +193,18 @@ class FocusedAttn(nn.Module):
     def _roi_attention_folded(self, q, k_tok, v_tok, pad, n_org, n_keys):
         b, n_q, c = q.shape
         qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
-        qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd)                       # sic: k_proj
-        w_k = self.k_proj.weight.view(h, hd, c).to(qq.dtype)
+        qq = (shadow.linear(q, self.k_proj.weight, self.k_proj.bias) * self.scale).view(b, n_org, qpo, h, hd)   # sic: k_proj
+        w_k = shadow.as_bf16(self.k_proj.weight).view(h, hd, c).to(qq.dtype)
         qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
         scores = _Scores.apply(qf, k_tok.view(b, n_org, n_keys, c).to(qf.dtype))             # (B, O, h*qpo, L)
         scores = scores.masked_fill(pad[None, :, None, :], float("-inf"))
         with torch.autocast(q.device.type, enabled=False):
             prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
         ctx = (prob @ v_tok.view(b, n_org, n_keys, c)).view(b, n_org, h, qpo, c)            # sum_k p_k x_k
-        w_v = self.v_proj.weight.view(h, hd, c).to(ctx.dtype)
+        w_v = shadow.as_bf16(self.v_proj.weight).view(h, hd, c).to(ctx.dtype)
         out = torch.einsum("bohqc,hdc->boqhd", ctx, w_v)
         if self.v_proj.bias is not None:
-            out = out + self.v_proj.bias.view(h, hd).to(out.dtype)
+            out = out + shadow.as_bf16(self.v_proj.bias).view(h, hd).to(out.dtype)
         return out.reshape(b, n_q, c)
 
     def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None, roi_cache=None):
@@ -212,7 +212,8 @@ class FocusedAttn(nn.Module):
         same mask as per-organ key lists.  k_pos: if given, the keys are
         ``v + k_pos`` and ``k`` may be None.  Returns (out, weights or None)."""
         if roi is not None and not need_weights and (k_pos is not None or k is v):
-            return self.proj_drop(self.proj(self._roi_attention(q, v, k_pos, roi, roi_cache))), None
+            x = self._roi_attention(q, v, k_pos, roi, roi_cache)
+            return self.proj_drop(shadow.linear(x, self.proj.weight, self.proj.bias)), None
         if k is None:
             k = v + k_pos
         b, n_kv, c = k.shape
@@ -336,8 +337,10 @@ class FocusedDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, src_pos, src, need_weights=False, roi_cache=None):
         q = k = tgt if query_pos is None else tgt + query_pos
-        sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
-                            need_weights=False)[0].transpose(0, 1)
+        sa = shadow.self_attention(self.self_attn, q, tgt)           # the step's bf16 weight mirrors, when there are
+        if sa is None:
+            sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
+                                need_weights=False)[0].transpose(0, 1)
         tgt = self.norm2(tgt + self.dropout2(sa))
 
         q = tgt if query_pos is None else tgt + query_pos
@@ -346,7 +349,8 @@ class FocusedDecoderLayer(nn.Module):
                                       need_weights=need_weights, roi=roi, k_pos=src_pos, roi_cache=roi_cache)
         tgt = self.norm1(tgt + self.dropout1(ca))
 
-        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        hidden = self.activation(shadow.linear(tgt, self.linear1.weight, self.linear1.bias))
+        ffn = shadow.linear(self.dropout3(hidden), self.linear2.weight, self.linear2.bias)
         return self.norm3(tgt + self.dropout4(ffn)), weights
 
 

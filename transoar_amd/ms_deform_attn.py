@@ -146,8 +146,9 @@ class MSDeformAttn(nn.Module):
         # both projections read `query`: one GEMM over the stacked weights (the
         # parameters stay separate, as in the reference's state dict)
         n_off = self.sampling_offsets.out_features
-        proj = token_linear(query, torch.cat((self.sampling_offsets.weight, self.attention_weights.weight)),
-                            torch.cat((self.sampling_offsets.bias, self.attention_weights.bias)))
+        proj = token_linear(query, self.sampling_offsets.weight,
+                            torch.cat((self.sampling_offsets.bias, self.attention_weights.bias)),
+                            weight2=self.attention_weights.weight)
         if self.use_cuda and _fused_usable(value, proj, reference_points, input_spatial_shapes, m, lv, pt, lq, s):
             # no gradient wanted (evaluation / inference): the sampling head runs in the gather's prologue and
             # neither locations nor weights are materialised (transoar_msda3d_forward_fused)

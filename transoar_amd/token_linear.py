@@ -23,7 +23,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import conv_gemm, gemm, rows
+from . import conv_gemm, gemm, rows, shadow
 
 MIN_TOKENS = 32768          # below this the stock path is as fast
 LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
@@ -72,11 +72,20 @@ def weight_grad(gy, x):
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, force_hip=False):
+    def forward(ctx, x, weight, bias, force_hip=False, weight2=None):
+        """weight2: a second parameter stacked under `weight` (one GEMM for two projections of the same input); its
+        rows follow weight's in the output, `bias` is then the caller's concatenation."""
         xb = x.to(torch.bfloat16)
-        wb = weight.to(torch.bfloat16)
+        # the step's bf16 mirror of the parameter (transoar_amd/shadow.py) instead of a cast kernel per call
+        if weight2 is None:
+            wb = shadow.bf16_or_cast(weight)
+        else:
+            wb = shadow.bf16_stack((weight, weight2))
+            if wb is None:
+                wb = torch.cat((weight, weight2)).to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
         ctx.in_dtype, ctx.has_bias, ctx.force_hip = x.dtype, bias is not None, force_hip
+        ctx.split = None if weight2 is None else weight.shape[0]
         global LAST_PATH
         x2 = xb.reshape(-1, xb.shape[-1])
         if _hip_gemm(x2, wb, force_hip):
@@ -85,7 +94,7 @@ class _TokenLinear(torch.autograd.Function):
             return gemm.linear_nt(x2, wb, bias).view(*xb.shape[:-1], wb.shape[0])
         LAST_PATH = "blas"
         with torch.autocast("cuda", enabled=False):
-            return F.linear(xb, wb, None if bias is None else bias.to(torch.bfloat16))
+            return F.linear(xb, wb, None if bias is None else shadow.bf16_or_cast(bias))
 
     @staticmethod
     def backward(ctx, gy):
@@ -100,20 +109,23 @@ class _TokenLinear(torch.autograd.Function):
                 wt = wb.t().contiguous()                   # (K, N): dX = dY . W as an NT product
                 gx = gemm.linear_nt(gy2, wt) if _hip_gemm(gy2, wt, ctx.force_hip) else torch.mm(gy2, wb)
                 gx = gx.view(xb.shape).to(ctx.in_dtype)
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] or (ctx.split is not None and ctx.needs_input_grad[4]):
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = rows.colsum(gy2) if rows.colsum_usable(gy2) else gy2.sum(0, dtype=torch.float32)
-        return gx, gw, gb, None
+        if ctx.split is not None and gw is not None:
+            return gx, gw[:ctx.split], gb, None, gw[ctx.split:]
+        return gx, gw, gb, None, None
 
 
-def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None):
+def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None, weight2=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
     bf16 autocast on the GPU with enough tokens, the stock one otherwise.  force_hip: the hand-written GEMM for
-    the forward and the data gradient whatever the shape (the FPN's 1x1x1 and transposed convolutions)."""
+    the forward and the data gradient whatever the shape (the FPN's 1x1x1 and transposed convolutions).
+    weight2: a second weight parameter stacked under `weight` (y = x [weight; weight2]^T + bias, bias already stacked)."""
     tokens = x.numel() // x.shape[-1]
     if (x.is_cuda and tokens >= (MIN_TOKENS if min_tokens is None else min_tokens)
             and weight.dtype == torch.float32 and x.is_contiguous()
             and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
-        return _TokenLinear.apply(x, weight, bias, force_hip)
-    return F.linear(x, weight, bias)
+        return _TokenLinear.apply(x, weight, bias, force_hip, weight2)
+    return F.linear(x, weight if weight2 is None else torch.cat((weight, weight2)), bias)

@@ -77,6 +77,21 @@ class TrainStep:
         if plan:
             plan.run()
 
+    def _shadow(self):
+        """The bf16 mirrors of the fp32 parameters (transoar_amd/shadow.py), refreshed: one multi-tensor copy per step
+        instead of a cast kernel per weight, per bias and per gradient.  None: switched off (TRANSOAR_SHADOW_WEIGHTS=0)."""
+        if os.environ.get("TRANSOAR_SHADOW_WEIGHTS", "1") == "0":
+            return None
+        reg = getattr(self, "_shadow_reg", None)
+        if reg is None or not reg.valid():
+            from .ms_deform_attn import MSDeformAttn
+            from .shadow import ShadowWeights
+            stacks = [(m.sampling_offsets.weight, m.attention_weights.weight)
+                      for m in self.model.modules() if isinstance(m, MSDeformAttn)]
+            reg = self._shadow_reg = ShadowWeights(self.model, stacks)
+        reg.refresh()
+        return reg
+
     def end_epoch(self):
         """Advance the learning-rate schedule (the reference steps it after every epoch, trainer.py:220).  The
         fused AdamW reads the group's lr on every step, so this is safe next to a captured graph."""
@@ -96,9 +111,13 @@ class TrainStep:
             counts = self.reducer.reduce_counts(counts)
             targets = DenseTargets(targets.boxes, targets.present, counts[0], counts[1])
         enabled = self.amp_dtype is not None and self.amp_dtype != torch.float32
+        mirrors = None
         if enabled and self.amp_dtype == torch.bfloat16 and data.is_cuda and torch.is_grad_enabled():
             self._prepack()
-        with torch.autocast(self.device_type, dtype=self.amp_dtype if enabled else torch.bfloat16, enabled=enabled):
+            mirrors = self._shadow()
+        from . import shadow
+        with shadow.fresh(mirrors), \
+                torch.autocast(self.device_type, dtype=self.amp_dtype if enabled else torch.bfloat16, enabled=enabled):
             out = self.model(data)
             losses = self.criterion(out, targets, seg_targets, self.model._anchors)
             coefs = self.config["loss_coefs"]

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import shadow
 from .backbone import AttnFPN
 from .criterion import TransoarCriterion
 from .focused_decoder import FocusedDecoder
@@ -58,8 +59,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for layer in self.layers[:-1]:
-            x = F.relu(layer(x))
-        return self.layers[-1](x)
+            x = F.relu(shadow.linear(x, layer.weight, layer.bias))
+        return shadow.linear(x, self.layers[-1].weight, self.layers[-1].bias)
 
 
 def generate_anchors(neck_config, bbox_props):
@@ -137,7 +138,7 @@ class TransoarNet(nn.Module):
         feats = self._backbone(x)
         det_src = feats[self._input_levels]
         hs = self._neck(det_src, self._query_embed.weight, self._pos_enc(det_src))   # (layers, N, Q, C)
-        logits = self._cls_head(hs)
+        logits = shadow.linear(hs, self._cls_head.weight, self._cls_head.bias)
         boxes = self._reg_head(hs)
         if self._anchor_offset:
             boxes = (boxes.tanh() * self._restrictions + self._anchors).clamp(min=0, max=1)
