@@ -85,6 +85,7 @@ struct ConvGeom {
 //          1, 2, 4 or 8 taps (per axis, parity 0: tap 1 of dy voxel m; parity 1: taps 0, 2 of dy voxels m + 1, m) and
 //          writes dx voxels 2 m + parity.  Tiles are numbered class by class, the eight-tap class first.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kInvalid = 0x40000000;            // 2^30: beyond every filter pack (check_geom)
 constexpr unsigned kTapsParity0 = 1u | (1u << 2) | (1u << 4);                                   // {(0, 1)}
 constexpr unsigned kTapsParity1 = 2u | (2u << 2) | (0u << 4) | (1u << 6) | (2u << 8);           // {(+1, 0), (0, 2)}
 
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
     int split, long n_tiles, int tiles_n, int classes, unsigned x_bytes, unsigned w_bytes) {
   constexpr int BNT = 64 * TN, NB = BNT / 32;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][kTile + BNT * BK * 2];
-  __shared__ int tap_src[27], tap_w[27], tap_e[27];
+  __shared__ int2 tap_tab[32];                 // {source offset, filter offset} per tap-list entry; entries >= ntaps: out of range
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long tile_id = xcd_contiguous(blockIdx.x, n_tiles * split);
   if (tile_id < 0) return;
@@ -122,11 +123,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   const int M = g.N * g.MD * g.MH * g.MW;
   const int nd = taps_count(tp_d), nh = taps_count(tp_h), nw = taps_count(tp_w);
   const int ntaps = nd * nh * nw;
-  if (tid < ntaps) {
-    const int ed = tid / (nh * nw), r = tid - ed * nh * nw, eh = r / nw, ew = r - eh * nw;
-    tap_src[tid] = ((taps_delta(tp_d, ed) * g.SH + taps_delta(tp_h, eh)) * g.SW + taps_delta(tp_w, ew)) * g.Cin * 2;
-    tap_w[tid] = ((taps_t(tp_d, ed) * 3 + taps_t(tp_h, eh)) * 3 + taps_t(tp_w, ew)) * g.Cout * g.Cin * 2;
-    tap_e[tid] = ed | (eh << 2) | (ew << 4);
+  if (tid < 32) {
+    int2 e{0, kInvalid};                                          // a piece past the end of K reads zeros from both operands
+    if (tid < ntaps) {
+      const int ed = tid / (nh * nw), r = tid - ed * nh * nw, eh = r / nw, ew = r - eh * nw;
+      e.x = ((taps_delta(tp_d, ed) * g.SH + taps_delta(tp_h, eh)) * g.SW + taps_delta(tp_w, ew)) * g.Cin * 2;
+      e.y = ((taps_t(tp_d, ed) * 3 + taps_t(tp_h, eh)) * 3 + taps_t(tp_w, ew)) * g.Cout * g.Cin * 2;
+    }
+    tap_tab[tid] = e;
   }
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, static_cast<int>(x_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wk), 0, static_cast<int>(w_bytes), 0x00020000);
@@ -145,31 +149,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   // staging: thread -> (row, 16-byte piece): 4 rows of the A tile, NB of the B tile
   const int s_piece = tid & 7, s_row = tid >> 3;                  // rows s_row + 32 i
   unsigned a_base[4], b_base[NB];
-  int a_mask[4];                                                  // validity of the row's sources: 3 bits per dimension, by tap-list entry
+  unsigned a_inv[4];               // bit e: the row's source of tap-list entry e lies in the padding (or the row does not exist);
+                                   // bits >= ntaps are set, so that a piece past the end of K is "padding" too
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + s_row + 32 * i;
-    a_mask[i] = 0;
+    unsigned ok = 0;
     a_base[i] = 0;
     if (m < M) {
       int nb, md, mh, mw;
       split_row(m, nb, md, mh, mw);
       const int sd = md * g.src_stride, sh = mh * g.src_stride, sw = mw * g.src_stride;
       a_base[i] = static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) * 2u;
-      int mask = 0;
+      // entry index = (ed * nh + eh) * nw + ew: the validity map is the outer product of the per-axis ones
+      unsigned wv = 0, hw = 0;
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        mask |= (e < nd && static_cast<unsigned>(sd + taps_delta(tp_d, e)) < static_cast<unsigned>(g.SD)) ? (1 << e) : 0;
-        mask |= (e < nh && static_cast<unsigned>(sh + taps_delta(tp_h, e)) < static_cast<unsigned>(g.SH)) ? (8 << e) : 0;
-        mask |= (e < nw && static_cast<unsigned>(sw + taps_delta(tp_w, e)) < static_cast<unsigned>(g.SW)) ? (64 << e) : 0;
-      }
-      a_mask[i] = mask;
+      for (int e = 0; e < 3; ++e)
+        wv |= (e < nw && static_cast<unsigned>(sw + taps_delta(tp_w, e)) < static_cast<unsigned>(g.SW)) ? (1u << e) : 0u;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        hw |= (e < nh && static_cast<unsigned>(sh + taps_delta(tp_h, e)) < static_cast<unsigned>(g.SH)) ? (wv << (e * nw)) : 0u;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        ok |= (e < nd && static_cast<unsigned>(sd + taps_delta(tp_d, e)) < static_cast<unsigned>(g.SD)) ? (hw << (e * nh * nw)) : 0u;
     }
+    a_inv[i] = ~ok;
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int n = n0 + s_row + 32 * i;
-    b_base[i] = n < g.Cout ? static_cast<unsigned>(n) * static_cast<unsigned>(g.Cin) * 2u : 0x80000000u;
+    b_base[i] = n < g.Cout ? static_cast<unsigned>(n) * static_cast<unsigned>(g.Cin) * 2u : static_cast<unsigned>(kInvalid);
   }
   __syncthreads();                                                // tap tables
 
@@ -180,22 +189,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   const int kt0 = ks * kt_per, kt1 = min(KT, kt0 + kt_per);
   const float inv_pt = 1.0f / static_cast<float>(PT);
 
-  u32x4 ra0[4], rb0[NB], ra1[4], rb1[NB];
+  // Branch-free addressing (round 3; the first version tested three mask bits per row behind a branch each: 9.4 VALU
+  // instructions per MFMA): the tap of this thread's piece indexes ONE packed table entry and ONE bit of the row's map;
+  // an invalid A source gets bit 31 set (past the buffer: zeros), an invalid filter piece the offset kInvalid (2^30,
+  // past any filter pack -- checked on the host -- also when row and piece are both invalid: 2^31).
+  u32x4 ra0[4], rb0[NB];
   auto load_tile = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[NB]) {
     const int j = kt * 8 + s_piece;                               // this thread's piece of the flattened (tap, channel) axis
-    const bool in_k = j < pieces;
-    const int tap = in_k ? static_cast<int>((static_cast<float>(j) + 0.5f) * inv_pt) : 0;
-    const int c8 = j - tap * PT;
-    const int src = tap_src[tap] + c8 * 16, wof = tap_w[tap] + c8 * 16, e = tap_e[tap];
-    const int ed = e & 3, eh = 3 + ((e >> 2) & 3), ew = 6 + (e >> 4);
+    const int tap = min(static_cast<int>((static_cast<float>(j) + 0.5f) * inv_pt), 31);      // j >= pieces -> tap >= ntaps
+    const int c8 = j - __mul24(tap, PT);
+    const int2 tt = tap_tab[tap];
+    const unsigned src = static_cast<unsigned>(tt.x + c8 * 16), wof = static_cast<unsigned>(tt.y + c8 * 16);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = in_k && ((a_mask[i] >> ed) & (a_mask[i] >> eh) & (a_mask[i] >> ew) & 1);
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? a_base[i] + static_cast<unsigned>(src) : 0x80000000u, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (a_base[i] + src) | (((a_inv[i] >> tap) & 1u) << 31), 0, 0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, in_k ? b_base[i] + static_cast<unsigned>(wof) : 0x80000000u, 0, 0);
+    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_base[i] + wof, 0, 0);
   };
   auto store_tile = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[NB]) {
 #pragma unroll
@@ -249,21 +258,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
         for (int b = 0; b < 2; ++b) acc[a][b] = mfma(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
     }
   };
+  // One register set: tile kt + 1 is written to the other LDS stage right after the barrier that freed it, tile kt + 2 is
+  // requested at once and flies during compute(kt).  Two K steps per trip with the odd one peeled AFTER the loop: the
+  // first version left the loop from its middle, and the compiler copied all 64 accumulator registers once per trip
+  // (32 v_mov_b64 behind the MFMAs they waited for).
   if (kt0 < kt1) {
     load_tile(kt0, ra0, rb0);
-    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra1, rb1);
     store_tile(0, ra0, rb0);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra0, rb0);
     block_barrier();
-    for (int kt = kt0; kt < kt1; kt += 2) {
+    int kt = kt0;
+    for (; kt + 2 <= kt1; kt += 2) {
+      if (kt + 1 < kt1) store_tile(1, ra0, rb0);               // always true here; keeps the two halves alike
       if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
       compute(0);
-      if (kt + 1 < kt1) store_tile(1, ra1, rb1);
       block_barrier();
-      if (kt + 1 >= kt1) break;
-      if (kt + 3 < kt1) load_tile(kt + 3, ra1, rb1);
-      compute(1);
       if (kt + 2 < kt1) store_tile(0, ra0, rb0);
+      if (kt + 3 < kt1) load_tile(kt + 3, ra0, rb0);
+      compute(1);
       block_barrier();
+    }
+    if (kt < kt1) {                                             // odd count: the last tile sits in stage 0
+      compute(0);
+      block_barrier();                                          // the epilogue reuses the stages
     }
   }
 
@@ -606,7 +623,7 @@ int check_geom(const ConvGeom& g) {
     return TRANSOAR_CONVGEMM_ERR_DIM;
   const long src = static_cast<long>(g.N) * g.SD * g.SH * g.SW * g.Cin * 2, out = static_cast<long>(g.N) * g.OD * g.OH * g.OW * g.Cout * 2;
   const long rows = static_cast<long>(g.N) * g.MD * g.MH * g.MW;
-  if (src >= 0x7ffffff0L || out >= 0x7ffffff0L * 2 || rows >= (1L << 31) || rows * g.Cout * 2 >= 0x7ffffff0L * 2 || 27L * g.Cout * g.Cin * 2 >= 0x7ffffff0L)
+  if (src >= 0x7ffffff0L || out >= 0x7ffffff0L * 2 || rows >= (1L << 31) || rows * g.Cout * 2 >= 0x7ffffff0L * 2 || 27L * g.Cout * g.Cin * 2 >= 0x3ffffff0L)
     return TRANSOAR_CONVGEMM_ERR_DIM;
   return 0;
 }
