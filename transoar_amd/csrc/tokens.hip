@@ -339,6 +339,124 @@ __global__ __launch_bounds__(256) void sampling_head_bwd(const float* __restrict
   }
 }
 
+// ---- the same two kernels for L = P = 4 (the flagship's 4 levels x 4 points), one thread per 16-BYTE PIECE of the
+// projection row: a token's row is 6 M pieces of offsets (8 coordinates each -> 32 bytes of locations) and 2 M pieces of
+// logits (half a head each; the two halves of a softmax sit in neighbouring lanes).  Consecutive threads read and write
+// consecutive pieces, so every access of a wave is one contiguous run (the per-element kernels above moved 2 to 4 bytes
+// per access behind three block barriers and two 64-bit divisions per element: 0.27 + 0.22 ms per call for 0.54 / 0.63 GB;
+// one thread per (token, head) with 16-byte accesses 192 bytes apart was no faster).  Same arithmetic in the same order.
+// A block holds a whole number of tokens; per-coordinate constants (bf16(size), index into the token's 12 reference
+// coordinates) and the block's reference points are staged in LDS.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kHeadMaxTok = 32;                  // tokens per block (<= 256 / (8 M))
+
+__global__ __launch_bounds__(256) void sampling_head_fwd_p16(const unsigned short* __restrict__ proj, const float* __restrict__ ref,
+                                                             const long* __restrict__ shapes, float* __restrict__ loc,
+                                                             float* __restrict__ attn, int M, unsigned tokens, unsigned ref_rows) {
+  constexpr int L = 4, P = 4, G = 16;
+  __shared__ float size_of[G * 3];               // by coordinate index inside a head: bf16((W, H, D)[k] of level l)
+  __shared__ int ref_of[G * 3];                  // l * 3 + k
+  __shared__ float ref_sh[kHeadMaxTok * L * 3];
+  const int ppt = 8 * M, tpb = blockDim.x / ppt;             // pieces per token, tokens per block
+  const unsigned t0 = blockIdx.x * tpb;
+  if (threadIdx.x < G * 3) {
+    const int idx = threadIdx.x, g = idx / 3, k = idx - 3 * g, l = g / P;
+    size_of[idx] = bf16_round(static_cast<float>(shapes[l * 3 + 2 - k]));
+    ref_of[idx] = l * 3 + k;
+  }
+  for (int i = threadIdx.x; i < tpb * L * 3; i += blockDim.x) {
+    const unsigned t = t0 + i / (L * 3);
+    ref_sh[i] = t < tokens ? ref[static_cast<long>(t % ref_rows) * (L * 3) + i % (L * 3)] : 0.f;
+  }
+  __syncthreads();
+  const int tl = threadIdx.x / ppt, p = threadIdx.x - tl * ppt;
+  const unsigned t = t0 + tl;
+  if (tl >= tpb || t >= tokens) return;
+  const u32x4_t v = reinterpret_cast<const u32x4_t*>(proj + static_cast<long>(t) * (4 * M * G))[p];
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { x[2 * j] = bf16_lo(w[j]); x[2 * j + 1] = bf16_hi(w[j]); }
+  if (p < 6 * M) {                               // offsets -> locations: ref + bf16(off / bf16(size))
+    const int c = p % 6;                         // piece inside the head: coordinates 8 c .. 8 c + 7
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = ref_sh[tl * (L * 3) + ref_of[8 * c + j]] + bf16_round(x[j] / size_of[8 * c + j]);
+    float4* dst = reinterpret_cast<float4*>(loc + static_cast<long>(t) * (M * G * 3) + p * 8);
+    dst[0] = float4{r[0], r[1], r[2], r[3]};
+    dst[1] = float4{r[4], r[5], r[6], r[7]};
+  } else {                                       // logits -> softmax; the other half of the head is lane ^ 1
+    const int q = p - 6 * M, half = q & 1;
+    float mx = x[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, x[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = __expf(x[j] - mx); if (half == 0) s += x[j]; }
+    const float s0 = __shfl_xor(s, 1);           // the first half's partial sum: the second half continues it in order
+    if (half == 1) {
+      s = s0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += x[j];
+    }
+    const float other = __shfl_xor(s, 1);
+    const float sum = half == 1 ? s : other;
+    float4* dst = reinterpret_cast<float4*>(attn + static_cast<long>(t) * (M * G) + q * 8);
+    dst[0] = float4{x[0] / sum, x[1] / sum, x[2] / sum, x[3] / sum};
+    dst[1] = float4{x[4] / sum, x[5] / sum, x[6] / sum, x[7] / sum};
+  }
+}
+
+__global__ __launch_bounds__(256) void sampling_head_bwd_p16(const float* __restrict__ g_loc, const float* __restrict__ g_attn,
+                                                             const float* __restrict__ attn, const long* __restrict__ shapes,
+                                                             unsigned short* __restrict__ g_proj, int M, unsigned tokens) {
+  constexpr int P = 4, G = 16;
+  __shared__ float size_of[G * 3];
+  const int ppt = 8 * M, tpb = blockDim.x / ppt;
+  if (threadIdx.x < G * 3) {
+    const int idx = threadIdx.x, g = idx / 3, k = idx - 3 * g, l = g / P;
+    size_of[idx] = bf16_round(static_cast<float>(shapes[l * 3 + 2 - k]));
+  }
+  __syncthreads();
+  const int tl = threadIdx.x / ppt, p = threadIdx.x - tl * ppt;
+  const unsigned t = blockIdx.x * tpb + tl;
+  if (tl >= tpb || t >= tokens) return;
+  unsigned h[8];
+  if (p < 6 * M) {
+    const int c = p % 6;
+    const float4* src = reinterpret_cast<const float4*>(g_loc + static_cast<long>(t) * (M * G * 3) + p * 8);
+    const float4 u = src[0], v = src[1];
+    const float gl[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = f32_to_bf16_bits(bf16_round(gl[j]) / size_of[8 * c + j]);
+  } else {
+    const int q = p - 6 * M, half = q & 1;
+    const long e = static_cast<long>(t) * (M * G) + q * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(attn + e), a1 = *reinterpret_cast<const float4*>(attn + e + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(g_attn + e), b1 = *reinterpret_cast<const float4*>(g_attn + e + 4);
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float ga[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float d = 0.f;
+    if (half == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += a[j] * ga[j];
+    }
+    const float d0 = __shfl_xor(d, 1);
+    if (half == 1) {
+      d = d0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += a[j] * ga[j];
+    }
+    const float other = __shfl_xor(d, 1);
+    const float dot = half == 1 ? d : other;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = f32_to_bf16_bits(a[j] * (ga[j] - dot));
+  }
+  reinterpret_cast<u32x4_t*>(g_proj + static_cast<long>(t) * (4 * M * G))[p] =
+      u32x4_t{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
 }  // namespace
 
 static unsigned keep_threshold(float keep_prob) {
@@ -443,6 +561,13 @@ extern "C" int transoar_sampling_head_forward(const void* proj, const float* ref
   if (tokens <= 0 || M <= 0 || L <= 0 || P <= 0 || L * P > 256 || ref_rows <= 0 || tokens % ref_rows) return TRANSOAR_TOK_ERR_DIM;
   const int G = L * P, threads = (256 / G) * G;
   const long n = tokens * M * G;
+  if (L == 4 && P == 4 && 8 * M <= 256 && tokens < (1L << 31) && ref_rows < (1L << 31)) {
+    const int tpb = 256 / (8 * M), threads_p = tpb * 8 * M;     // a whole number of tokens per block
+    hipLaunchKernelGGL(sampling_head_fwd_p16, dim3(static_cast<unsigned>((tokens + tpb - 1) / tpb)), dim3(threads_p), 0,
+                       static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(proj), ref, shapes, loc, attn, M,
+                       static_cast<unsigned>(tokens), static_cast<unsigned>(ref_rows));
+    return static_cast<int>(hipGetLastError());
+  }
   hipLaunchKernelGGL(sampling_head_fwd, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(proj), ref, shapes, loc, attn,
                      M, L, P, n, ref_rows);
@@ -456,6 +581,13 @@ extern "C" int transoar_sampling_head_backward(const float* g_loc, const float* 
   if (tokens <= 0 || M <= 0 || L <= 0 || P <= 0 || L * P > 256) return TRANSOAR_TOK_ERR_DIM;
   const int G = L * P, threads = (256 / G) * G;
   const long n = tokens * M * G;
+  if (L == 4 && P == 4 && 8 * M <= 256 && tokens < (1L << 31)) {
+    const int tpb = 256 / (8 * M), threads_p = tpb * 8 * M;
+    hipLaunchKernelGGL(sampling_head_bwd_p16, dim3(static_cast<unsigned>((tokens + tpb - 1) / tpb)), dim3(threads_p), 0,
+                       static_cast<hipStream_t>(hip_stream), g_loc, g_attn, attn, shapes, static_cast<unsigned short*>(g_proj), M,
+                       static_cast<unsigned>(tokens));
+    return static_cast<int>(hipGetLastError());
+  }
   hipLaunchKernelGGL(sampling_head_bwd, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
                      static_cast<hipStream_t>(hip_stream), g_loc, g_attn, attn, shapes, static_cast<unsigned short*>(g_proj),
                      M, L, P, n);
