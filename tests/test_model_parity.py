@@ -131,7 +131,7 @@ def test_g6_backbone(golden_dir, debug_core, device, tag, refine):
         # checksums of fp32 gradients through 12 InstanceNorm layers are ill-conditioned (see
         # tests/test_data_parallel.py): 2e-4 of sum|g| CPU-vs-CPU, 5e-3 CPU golden vs GPU kernels
         tol = 2e-4 if device == "cpu" else 5e-3
-        assert abs(got - s) <= tol * max(a, 1e-6) + 1e-7, name
+        assert abs(got - s) <= tol * max(a, 1e-6) + 1e-7, (name, got, float(s), float(a))
 
 
 @pytest.mark.parametrize("device", _device_params())

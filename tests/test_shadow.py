@@ -68,3 +68,37 @@ def test_step_with_mirrors_matches_step_with_casts():
     assert worst[0][0] <= 4e-2, worst[:5]
     rest = [w for w in worst if not w[1].startswith("_backbone._encoder.")]
     assert rest[0][0] <= 1.5e-2, rest[:5]
+
+
+@pytest.mark.gpu
+def test_shared_token_gradient_matches_autograd_chain():
+    """Focused Decoder cross-attention with keys = values + sine positions: the single token gradient of _FoldedCore
+    (dS^T qf + P^T dctx accumulated in one buffer, handed to the values) against autograd's separate key / value chains."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from test_train_step_gpu import _batch, _flagship
+    from transoar_amd.focused_decoder import FocusedAttn
+    from transoar_amd.train_step import TrainStep, build_optimizer
+    cfg, model, crit = _flagship()
+    step = TrainStep(model, crit, cfg, optimizer=build_optimizer(model, cfg), amp_dtype=torch.bfloat16, graph=False)
+    x, t = _batch(cfg, 2)
+    params = {n: p for n, p in model.named_parameters() if p.requires_grad}
+    grads, losses = {}, {}
+    assert FocusedAttn.shared_token_grad
+    try:
+        for mode in (False, True):
+            FocusedAttn.shared_token_grad = mode
+            model.zero_grad(set_to_none=True)
+            total, _ = step._eager_fwd_bwd(x, t)
+            losses[mode] = float(total)
+            grads[mode] = {n: p.grad.detach().double().clone() for n, p in params.items() if p.grad is not None}
+    finally:
+        FocusedAttn.shared_token_grad = True
+    assert set(grads[False]) == set(grads[True])
+    assert abs(losses[False] - losses[True]) <= 1e-3 * abs(losses[False]), losses        # same forward arithmetic
+    worst = sorted(((float((grads[True][n] - g).norm() / g.norm().clamp_min(1e-30)), n) for n, g in grads[False].items()),
+                   reverse=True)
+    print("shared token gradient vs autograd chain, gradient rel-L2 worst:", worst[:4])
+    assert worst[0][0] <= 4e-2, worst[:5]
+    rest = [w for w in worst if not w[1].startswith("_backbone._encoder.")]
+    assert rest[0][0] <= 1.5e-2, rest[:5]

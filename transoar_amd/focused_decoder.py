@@ -95,6 +95,37 @@ class _Scores(torch.autograd.Function):
         return dq, dk
 
 
+class _FoldedCore(torch.autograd.Function):
+    """ctx = softmax(mask(qf k^T)) v over each organ's gathered tokens, for keys k = v + (input-independent positions):
+    the token gradient dS^T qf + P^T dctx is one GEMM plus one accumulating GEMM into the same buffer, handed to v alone
+    (the gradient of k IS a gradient of v).  Autograd's route built dk and dv separately and then added 170-MB tensors
+    five times per step (k-chain and v-chain over three layers, and the two chains into each other)."""
+
+    @staticmethod
+    def forward(ctx, qf, k_tok, v_tok, pad):
+        scores = qf @ k_tok.transpose(-1, -2)                         # (B, O, R, L)
+        scores.masked_fill_(pad[None, :, None, :], float("-inf"))
+        prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
+        ctx.save_for_backward(qf, k_tok, v_tok, prob)
+        return prob @ v_tok
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qf, k_tok, v_tok, prob = ctx.saved_tensors
+        dctx = dctx.to(prob.dtype)
+        dprob = dctx @ v_tok.transpose(-1, -2)
+        ds = torch._softmax_backward_data(dprob, prob, -1, prob.dtype)
+        dqf = ds @ k_tok if ctx.needs_input_grad[0] else None
+        dtok = None
+        if ctx.needs_input_grad[2]:
+            b, o, r, c = qf.shape
+            n_keys = k_tok.shape[2]
+            dtok = torch.bmm(ds.reshape(b * o, r, n_keys).transpose(1, 2), qf.reshape(b * o, r, c))
+            dtok.baddbmm_(prob.reshape(b * o, r, n_keys).transpose(1, 2), dctx.reshape(b * o, r, c))
+            dtok = dtok.view(b, o, n_keys, c)
+        return dqf, None, dtok, None
+
+
 class FocusedAttn(nn.Module):
     def __init__(self, dim, num_heads, attn_mask, qkv_bias=None, qk_scale=None, attn_drop=0,
                  proj_drop=0, use_pos_bias=False, return_weights=True):
@@ -164,7 +195,9 @@ class FocusedAttn(nn.Module):
         # (GPU only: on the CPU the 8x larger contraction of the folded form is slower than two projections)
         if FocusedAttn.fold_projections and q.is_cuda and self.pos_bias is None \
                 and not (self.training and self.attn_drop.p > 0):
-            return self._roi_attention_folded(q, k_tok, v_tok, pad, n_org, n_keys)
+            # keys = values + positions that depend neither on the input nor on parameters (sine encoding), or the values themselves
+            follow = FocusedAttn.shared_token_grad and (k_pos is None or is_constant(k_pos))
+            return self._roi_attention_folded(q, k_tok, v_tok, pad, n_org, n_keys, follow)
         kk = token_linear(k_tok, self.k_proj.weight, self.k_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         vv = token_linear(v_tok, self.v_proj.weight, self.v_proj.bias).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
         qq = (self.k_proj(q) * self.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)   # sic: k_proj
@@ -189,18 +222,25 @@ class FocusedAttn(nn.Module):
     # tokens (dimension C), two batched GEMMs each way, and neither K nor V (B*O*L x C each, plus their
     # data and weight gradient GEMMs over 2*10^5 tokens) is ever formed.  Same arithmetic up to association.
     fold_projections = os.environ.get("TRANSOAR_ROI_FOLD", "1") != "0"
+    shared_token_grad = os.environ.get("TRANSOAR_ROI_SHARED_GRAD", "1") != "0"      # _FoldedCore
 
-    def _roi_attention_folded(self, q, k_tok, v_tok, pad, n_org, n_keys):
+    def _roi_attention_folded(self, q, k_tok, v_tok, pad, n_org, n_keys, keys_follow_values=False):
         b, n_q, c = q.shape
         qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
         qq = (shadow.linear(q, self.k_proj.weight, self.k_proj.bias) * self.scale).view(b, n_org, qpo, h, hd)   # sic: k_proj
         w_k = shadow.as_bf16(self.k_proj.weight).view(h, hd, c).to(qq.dtype)
         qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
-        scores = _Scores.apply(qf, k_tok.view(b, n_org, n_keys, c).to(qf.dtype))             # (B, O, h*qpo, L)
-        scores = scores.masked_fill(pad[None, :, None, :], float("-inf"))
-        with torch.autocast(q.device.type, enabled=False):
-            prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
-        ctx = (prob @ v_tok.view(b, n_org, n_keys, c)).view(b, n_org, h, qpo, c)            # sum_k p_k x_k
+        if keys_follow_values and k_tok.dtype == qf.dtype and v_tok.dtype == qf.dtype:
+            # k = v + constant positions: one token gradient (see _FoldedCore)
+            with torch.autocast(q.device.type, enabled=False):
+                ctx = _FoldedCore.apply(qf, k_tok.detach().view(b, n_org, n_keys, c), v_tok.view(b, n_org, n_keys, c), pad)
+            ctx = ctx.view(b, n_org, h, qpo, c)
+        else:
+            scores = _Scores.apply(qf, k_tok.view(b, n_org, n_keys, c).to(qf.dtype))             # (B, O, h*qpo, L)
+            scores = scores.masked_fill(pad[None, :, None, :], float("-inf"))
+            with torch.autocast(q.device.type, enabled=False):
+                prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
+            ctx = (prob @ v_tok.view(b, n_org, n_keys, c)).view(b, n_org, h, qpo, c)            # sum_k p_k x_k
         w_v = shadow.as_bf16(self.v_proj.weight).view(h, hd, c).to(ctx.dtype)
         out = torch.einsum("bohqc,hdc->boqhd", ctx, w_v)
         if self.v_proj.bias is not None:
