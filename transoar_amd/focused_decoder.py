@@ -228,7 +228,7 @@ class FocusedAttn(nn.Module):
         b, n_q, c = q.shape
         qpo, h, hd = n_q // n_org, self.num_heads, c // self.num_heads
         qq = (shadow.linear(q, self.k_proj.weight, self.k_proj.bias) * self.scale).view(b, n_org, qpo, h, hd)   # sic: k_proj
-        w_k = shadow.as_bf16(self.k_proj.weight).view(h, hd, c).to(qq.dtype)
+        w_k = shadow.as_dtype(self.k_proj.weight, qq.dtype).view(h, hd, c)
         qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
         if keys_follow_values and k_tok.dtype == qf.dtype and v_tok.dtype == qf.dtype:
             # k = v + constant positions: one token gradient (see _FoldedCore)
@@ -241,10 +241,10 @@ class FocusedAttn(nn.Module):
             with torch.autocast(q.device.type, enabled=False):
                 prob = torch.softmax(scores, dim=-1)        # keeps the score dtype (bf16 under autocast; fp32 accumulation inside)
             ctx = (prob @ v_tok.view(b, n_org, n_keys, c)).view(b, n_org, h, qpo, c)            # sum_k p_k x_k
-        w_v = shadow.as_bf16(self.v_proj.weight).view(h, hd, c).to(ctx.dtype)
+        w_v = shadow.as_dtype(self.v_proj.weight, ctx.dtype).view(h, hd, c)
         out = torch.einsum("bohqc,hdc->boqhd", ctx, w_v)
         if self.v_proj.bias is not None:
-            out = out + shadow.as_bf16(self.v_proj.bias).view(h, hd).to(out.dtype)
+            out = out + shadow.as_dtype(self.v_proj.bias, out.dtype).view(h, hd)
         return out.reshape(b, n_q, c)
 
     def forward(self, q, k, v, mask=None, need_weights=False, roi=None, k_pos=None, roi_cache=None):

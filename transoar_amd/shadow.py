@@ -179,6 +179,12 @@ def as_bf16(p):
     return p.to(torch.bfloat16) if m is None else _AsBf16.apply(p)
 
 
+def as_dtype(p, dtype):
+    """p.to(dtype) with autograd: the mirror for bf16 inside a training step, the parameter itself (no detour through
+    bf16: the fp32 evaluation path must not round its weights) for every other dtype."""
+    return as_bf16(p) if dtype == torch.bfloat16 else p.to(dtype)
+
+
 class _SelfAttnProj(torch.autograd.Function):
     """The packed input projection of nn.MultiheadAttention for self-attention with q = k = x_qk and v = x_v:
     (x_qk W[:2C]^T + b[:2C], x_v W[2C:]^T + b[2C:]) from the mirrors; the gradient of the packed weight is assembled
