@@ -102,3 +102,26 @@ def test_shared_token_gradient_matches_autograd_chain():
     assert worst[0][0] <= 4e-2, worst[:5]
     rest = [w for w in worst if not w[1].startswith("_backbone._encoder.")]
     assert rest[0][0] <= 1.5e-2, rest[:5]
+
+
+@pytest.mark.parametrize("follow", [False, True])
+def test_folded_attention_keeps_fp32_weights_outside_autocast(follow):
+    """The folded per-organ attention against explicit K / V projections in fp32 (no autocast, no mirrors): the weights
+    must enter unrounded (a detour through bf16 here cost the fp32 GPU parity of golden g7 a factor 10)."""
+    from transoar_amd.focused_decoder import FocusedAttn
+    torch.manual_seed(3)
+    b, n_org, qpo, n_keys, c, h = 2, 3, 4, 10, 32, 4
+    attn = FocusedAttn(c, h, torch.zeros(n_org * qpo, 1), qkv_bias=True).eval()
+    q = torch.randn(b, n_org * qpo, c)
+    v_tok = torch.randn(b, n_org * n_keys, c)
+    k_tok = v_tok + 0.3 * torch.randn(1, n_org * n_keys, c)
+    pad = torch.zeros(n_org, n_keys, dtype=torch.bool)
+    pad[1, 7:] = True
+    got = attn._roi_attention_folded(q, k_tok, v_tok, pad, n_org, n_keys, follow)
+    hd = c // h
+    kk = attn.k_proj(k_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+    vv = attn.v_proj(v_tok).view(b, n_org, n_keys, h, hd).permute(0, 1, 3, 2, 4)
+    qq = (attn.k_proj(q) * attn.scale).view(b, n_org, qpo, h, hd).permute(0, 1, 3, 2, 4)
+    p = (qq @ kk.transpose(-2, -1)).masked_fill(pad[None, :, None, None, :], float("-inf")).softmax(-1)
+    want = (p @ vv).permute(0, 1, 3, 2, 4).reshape(b, n_org * qpo, c)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
