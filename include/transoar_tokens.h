@@ -77,6 +77,20 @@ int transoar_relu_dropout_backward(const void* gy, const void* y, float keep_sca
                                    void* hip_stream);
 int transoar_add_layernorm_partial_rows(void);
 
+/*
+ * Query of the first layer of the refine block (decoder_blocks.py:76-83 + with_pos_embed :157-158, applied to the
+ * pyramid tokens themselves):  q16 = bf16(x16 + (pos_sine[s] + level_embed[l(s)]))  with x16 (rows, cols) bf16 --
+ * the rounding points of the eager chain (fp32 sum of the positional terms, fp32 add, one rounding).
+ * backward: the gradient of x16 is gq16 itself; partials (transoar_pos_query_partial_rows(), L, cols) fp32, written
+ * completely, hold per workgroup the per-level column sums of gq16 (-> d level_embed: the caller sums over dim 0).
+ */
+int transoar_pos_query_forward(const void* x16, const float* pos_sine, const float* level_embed,
+                               const int* level_start, int L, long S, void* q16, long rows, int cols,
+                               void* hip_stream);
+int transoar_pos_query_backward(const void* gq16, const int* level_start, int L, long S, float* partials,
+                                long rows, int cols, void* hip_stream);
+int transoar_pos_query_partial_rows(void);
+
 /* Head of MSDeformAttn.forward (transoar/models/ops/modules/ms_deform_attn.py:114-128): from the stacked
  * projection proj (tokens, 4*M*L*P) bf16 = [sampling_offsets (M, L, P, 3) | attention_weights logits (M, L*P)],
  *     loc  (tokens, M, L, P, 3) fp32 = ref (ref_rows, L, 3)[token % ref_rows] + bf16(offset / bf16(W_l, H_l, D_l))

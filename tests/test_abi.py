@@ -121,6 +121,15 @@ def test_sampling_head_and_colsum_argument_errors():
     b = tok.transoar_sampling_head_backward
     b.argtypes = [p, p, p, p, p, lg, i, i, i, p]
     assert b(p16, p16, None, p16, p16, 4, 6, 4, 4, None) == -1
+    q = tok.transoar_pos_query_forward
+    q.argtypes = [p, p, p, p, i, lg, p, lg, i, p]
+    assert q(None, p16, p16, p16, 4, 8, p16, 16, 384, None) == -1
+    assert q(p16, p16, p16, p16, 4, 8, p16, 16, 200, None) == -2           # cols not a multiple of 128
+    assert q(p16, p16, p16, p16, 9, 8, p16, 16, 384, None) == -3           # more than TRANSOAR_TOK_MAX_LEVELS
+    qb = tok.transoar_pos_query_backward
+    qb.argtypes = [p, p, i, lg, p, lg, i, p]
+    assert qb(p16, p16, 4, 8, None, 16, 384, None) == -1
+    assert tok.transoar_pos_query_partial_rows() > 0 and tok.transoar_tokens_abi_version() == 5
     c = rows.transoar_rows_colsum
     c.argtypes = [p, p, p, lg, i, p]
     assert c(None, p16, p16, 8, 8, None) == -1

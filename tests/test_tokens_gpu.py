@@ -210,3 +210,34 @@ def test_dropout_seed_changes_on_every_graph_replay():
         torch.cuda.synchronize()
         seen.add(int(out.item()))
     assert len(seen) == 4, seen
+
+
+@pytest.mark.parametrize("cols", [128, 384, 1024])
+def test_pos_query_matches_the_eager_chain(cols):
+    """First-layer query of the refine block: bit-equal to round(tokens + (sine + level embedding)); the tokens'
+    gradient is the query's, level_embed's the per-level column sums."""
+    from transoar_amd import tokens
+    torch.manual_seed(1)
+    n, sizes, dev = 2, [1100, 170, 23, 5], "cuda"
+    s_tok = sum(sizes)
+    x0 = torch.randn(n, s_tok, cols, device=dev).to(torch.bfloat16)
+    pos_sine = torch.randn(s_tok, cols, device=dev)
+    le0 = torch.randn(len(sizes), cols, device=dev)
+    starts = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=dev)
+    gq = torch.randn(n, s_tok, cols, device=dev).to(torch.bfloat16)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        le = le0.clone().requires_grad_(True)
+        if fused:
+            q = tokens.pos_query(x, pos_sine, le, starts)
+        else:
+            level_pos = torch.cat([le[l].expand(n_l, -1) for l, n_l in enumerate(sizes)], 0)
+            q = (x + (pos_sine + level_pos)).to(torch.bfloat16)
+        q.backward(gq)
+        return q, x.grad, le.grad
+
+    (q, gx, gle), (q_ref, gx_ref, gle_ref) = run(True), run(False)
+    assert q.dtype == torch.bfloat16 and torch.equal(q, q_ref)
+    assert torch.equal(gx, gx_ref)
+    assert (gle - gle_ref).abs().max().item() <= 1e-4 * gle_ref.abs().max().item()

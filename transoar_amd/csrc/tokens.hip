@@ -228,6 +228,92 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
   }
 }
 
+// Query of the FIRST refine layer: q16 = bf16(x + (pos_sine[s] + level_embed[level(s)])) from the bf16 pyramid tokens
+// (the later layers get theirs from add_ln_fwd).  One thread per 8 consecutive columns: 16-byte loads of x, 2 x 16
+// bytes of each fp32 operand, one 16-byte store.  Same rounding points as the eager chain (fp32 sum of the two
+// positional terms, fp32 add, one rounding).
+__global__ __launch_bounds__(256) void pos_query_fwd(const uint4* __restrict__ x16, const float* __restrict__ pos_sine,
+                                                     const float* __restrict__ level_embed,
+                                                     const int* __restrict__ level_start, int L, long S, int cols8,
+                                                     uint4* __restrict__ q16, long n8) {
+  const long g = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (g >= n8) return;
+  const long row = g / cols8;
+  const int c = static_cast<int>(g - row * cols8) * 8;
+  const long srow = row % S;
+  const int lvl = level_of(level_start, L, static_cast<int>(srow));
+  const int cols = cols8 * 8;
+  const uint4 x = x16[g];
+  const float4 p0 = *reinterpret_cast<const float4*>(pos_sine + srow * cols + c);
+  const float4 p1 = *reinterpret_cast<const float4*>(pos_sine + srow * cols + c + 4);
+  const float4 e0 = *reinterpret_cast<const float4*>(level_embed + lvl * cols + c);
+  const float4 e1 = *reinterpret_cast<const float4*>(level_embed + lvl * cols + c + 4);
+  uint4 q;
+  q.x = pack_bf16(bf16_lo(x.x) + (p0.x + e0.x), bf16_hi(x.x) + (p0.y + e0.y));
+  q.y = pack_bf16(bf16_lo(x.y) + (p0.z + e0.z), bf16_hi(x.y) + (p0.w + e0.w));
+  q.z = pack_bf16(bf16_lo(x.z) + (p1.x + e1.x), bf16_hi(x.z) + (p1.y + e1.y));
+  q.w = pack_bf16(bf16_lo(x.w) + (p1.z + e1.z), bf16_hi(x.w) + (p1.w + e1.w));
+  q16[g] = q;
+}
+
+// Its backward for level_embed: column sums of gq16 per level (the gradient of x is gq16 itself).  Persistent waves,
+// one row per wave and trip (two rows in flight), the level sums in registers (the level is uniform per row), reduced
+// over the workgroup's waves through LDS: partials (workgroups, L, cols) fp32, written completely.
+template <int K>
+__global__ __launch_bounds__(64 * kWaves) void pos_query_bwd(const unsigned int* __restrict__ gq16,
+                                                             const int* __restrict__ level_start, int L, long S,
+                                                             float* __restrict__ partials, long rows) {
+  constexpr int cols = 128 * K;
+  __shared__ float red[kWaves][cols];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long wave = static_cast<long>(blockIdx.x) * kWaves + wv;
+  float dle[TRANSOAR_TOK_MAX_LEVELS][2 * K];
+#pragma unroll
+  for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) dle[l][i] = 0.f;
+  for (long row = wave; row < rows; row += 2 * kPersistentWaves) {
+    const long row2 = row + kPersistentWaves;
+    const bool two = row2 < rows;
+    unsigned int u[K], v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      u[i] = gq16[(row * cols + i * 128 + 2 * lane) >> 1];
+      v[i] = two ? gq16[(row2 * cols + i * 128 + 2 * lane) >> 1] : 0u;
+    }
+    const int lvl = level_of(level_start, L, static_cast<int>(row % S));
+    const int lvl2 = two ? level_of(level_start, L, static_cast<int>(row2 % S)) : 0;
+#pragma unroll
+    for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l) {
+      if (l == lvl) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { dle[l][2 * i] += bf16_lo(u[i]); dle[l][2 * i + 1] += bf16_hi(u[i]); }
+      }
+      if (l == lvl2) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { dle[l][2 * i] += bf16_lo(v[i]); dle[l][2 * i + 1] += bf16_hi(v[i]); }
+      }
+    }
+  }
+  float* out = partials + static_cast<long>(blockIdx.x) * L * cols;
+#pragma unroll
+  for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l) {
+    if (l < L) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+        *reinterpret_cast<float2*>(&red[wv][i * 128 + 2 * lane]) = float2{dle[l][2 * i], dle[l][2 * i + 1]};
+      __syncthreads();
+      for (int c = threadIdx.x; c < cols; c += 64 * kWaves) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += red[w][c];
+        out[l * cols + c] = t;
+      }
+    }
+  }
+}
+
 // y = keep ? relu(h) * scale : 0 on bf16, 8 elements per thread
 __global__ __launch_bounds__(256) void relu_dropout_fwd(const uint4* __restrict__ h, KeepSrc keep, float scale,
                                                         uint4* __restrict__ y, long n8) {
@@ -594,5 +680,34 @@ extern "C" int transoar_sampling_head_backward(const float* g_loc, const float* 
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_pos_query_forward(const void* x16, const float* pos_sine, const float* level_embed,
+                                          const int* level_start, int L, long S, void* q16, long rows, int cols,
+                                          void* hip_stream) {
+  if (!x16 || !pos_sine || !level_embed || !level_start || !q16) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
+  if (L <= 0 || L > TRANSOAR_TOK_MAX_LEVELS) return TRANSOAR_TOK_ERR_LEVELS;
+  const long n8 = rows * (cols / 8);
+  hipLaunchKernelGGL(pos_query_fwd, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(x16), pos_sine, level_embed,
+                     level_start, L, S, cols / 8, static_cast<uint4*>(q16), n8);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_pos_query_backward(const void* gq16, const int* level_start, int L, long S, float* partials,
+                                           long rows, int cols, void* hip_stream) {
+  if (!gq16 || !level_start || !partials) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || cols % 128 || cols > 1024 || S <= 0) return TRANSOAR_TOK_ERR_DIM;
+  if (L <= 0 || L > TRANSOAR_TOK_MAX_LEVELS) return TRANSOAR_TOK_ERR_LEVELS;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(kPersistentWaves / kWaves), block(64 * kWaves);
+  auto g = static_cast<const unsigned int*>(gq16);
+  TOK_DISPATCH(cols / 128, {
+    hipLaunchKernelGGL((pos_query_bwd<K>), grid, block, 0, st, g, level_start, L, S, partials, rows);
+  });
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_pos_query_partial_rows(void) { return kPersistentWaves / kWaves; }
+
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 4; }
+extern "C" int transoar_tokens_abi_version(void) { return 5; }

@@ -37,9 +37,13 @@ class _MapToTokens(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .conv3d import to_ncdhw
+        from .conv3d import Conv3dK3, to_ncdhw
         n, c, d, h, w = ctx.shape
         g = g.contiguous().view(n, d, h, w, c).permute(0, 4, 1, 2, 3)      # channels_last_3d view
+        if Conv3dK3.ndhwc_everywhere and g.dtype == torch.bfloat16:
+            # the producer is a channels-last convolution whose backward reads NDHWC: the view is its gradient as it
+            # wants it (an NCDHW copy here was turned back by the convolution: two passes over every level)
+            return g
         return to_ncdhw(g) if g.dtype == torch.bfloat16 else g.contiguous()
 
 
@@ -183,6 +187,8 @@ class DecoderDefAttnBlock(nn.Module):
         # views into the token matrix (batch stride = the whole pyramid): no copies, the levels nobody reads cost nothing
         return [tokens_to_map(m, shape) for m, shape in zip(memory.split(sizes, dim=1), shapes)]
 
+    bf16_out = os.environ.get("TRANSOAR_REFINE_FP32_OUT", "0") != "1"
+
     def _fused_ok(self, tokens, pos_embeds):
         return (tokens.is_cuda and tokens.dtype == torch.bfloat16 and tokens.is_contiguous()
                 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
@@ -201,15 +207,19 @@ class DecoderDefAttnBlock(nn.Module):
         pos_sine, starts32 = const
         pos_pack = (pos_sine, self.level_embed, starts32)
         layers = self.refine_def_attn.layers
-        # first layer: query = round(tokens + pos) the stock way (one pass over the bf16 tokens)
-        # (expand + cat, not level_embed[level_of_token]: an indexed gather's backward is a sort-based index_put)
-        level_pos = torch.cat([self.level_embed[l].to(pos_sine.dtype).expand(n_l, -1) for l, n_l in enumerate(sizes)], 0)
-        q16 = (tokens + (pos_sine + level_pos)).to(torch.bfloat16)
+        # first layer: query = round(tokens + (sine + level embedding)) in one pass (tokens.pos_query; the eager chain
+        # wrote the 180-MB positional tensor and a 360-MB fp32 sum, and reduced their gradients level by level)
+        q16 = fused_tokens.pos_query(tokens, pos_sine, self.level_embed, starts32)
         x, x16 = tokens, tokens
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
             x, x16, q16 = layer.forward_fused(x, x16, q16, ref, spatial, starts, () if last else pos_pack)
-        return x
+        # bf16_out: hand on the bf16 rounding of the last LayerNorm output (made in the same pass) instead of the fp32
+        # tensor.  Under bf16 autocast every consumer of the refined maps (the Focused Decoder's token GEMMs, a
+        # convolution) rounds them to bf16 first, so the values it sees are the same; what disappears is that cast,
+        # its backward, and the 360-MB fp32 gradient of the whole pyramid that autograd zero-fills around the one
+        # level the detector reads.  TRANSOAR_REFINE_FP32_OUT=1 returns the fp32 tensor (the reference's dtype).
+        return x16 if DecoderDefAttnBlock.bf16_out else x
 
     def _pos_tokens(self, pos_map, lvl):
         """(N, C, D, H, W) positional map -> (N, V, C) tokens; the sine encoding

@@ -36,14 +36,20 @@ def _load():
     lib.transoar_sampling_head_forward.argtypes = [p, p, lg, p, p, p, lg, i, i, i, p]
     lib.transoar_sampling_head_backward.restype = i
     lib.transoar_sampling_head_backward.argtypes = [p, p, p, p, p, lg, i, i, i, p]
+    lib.transoar_pos_query_forward.restype = i
+    lib.transoar_pos_query_forward.argtypes = [p, p, p, p, i, lg, p, lg, i, p]
+    lib.transoar_pos_query_backward.restype = i
+    lib.transoar_pos_query_backward.argtypes = [p, p, i, lg, p, lg, i, p]
+    lib.transoar_pos_query_partial_rows.restype = i
     lib.transoar_tokens_abi_version.restype = i
-    if lib.transoar_tokens_abi_version() != 4:
+    if lib.transoar_tokens_abi_version() != 5:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
 
 lib = _load()
 PARTIAL_ROWS = lib.transoar_add_layernorm_partial_rows()
+POS_QUERY_PARTIAL_ROWS = lib.transoar_pos_query_partial_rows()
 
 
 def usable(x, r, cols):
@@ -70,6 +76,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, r, weight, bias, eps, pos_sine, level_embed, level_start, keep, keep_scale):
+        ctx.set_materialize_grads(False)          # an unused output (y32 of the last layer) costs no 360-MB zero gradient
         cols = x.shape[-1]
         rows = x.numel() // cols
         with_q = pos_sine is not None
@@ -172,6 +179,49 @@ def add_layernorm(x, r, norm, pos_sine=None, level_embed=None, level_start=None,
         keep = dropout_seed(r) if SEEDED_DROPOUT else dropout_mask(r, dropout.p)
         scale = 1.0 / (1.0 - dropout.p)
     return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps, pos_sine, level_embed, level_start, keep, scale)
+
+
+class _PosQuery(torch.autograd.Function):
+    """(x16 (..., S, C) bf16, pos_sine (S, C) fp32, level_embed (L, C), level_start (L,) int32) -> q16 bf16"""
+
+    @staticmethod
+    def forward(ctx, x16, pos_sine, level_embed, level_start):
+        cols = x16.shape[-1]
+        rows = x16.numel() // cols
+        le32 = level_embed.float().contiguous()
+        q16 = torch.empty_like(x16)
+        with torch.cuda.device(x16.device):
+            rc = lib.transoar_pos_query_forward(x16.data_ptr(), pos_sine.data_ptr(), le32.data_ptr(),
+                                                level_start.data_ptr(), le32.shape[0], pos_sine.shape[0],
+                                                q16.data_ptr(), rows, cols, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_pos_query_forward failed with code %d" % rc)
+        ctx.save_for_backward(level_start)
+        ctx.dims = (rows, cols, le32.shape[0], pos_sine.shape[0], level_embed.dtype)
+        return q16
+
+    @staticmethod
+    def backward(ctx, gq):
+        level_start, = ctx.saved_tensors
+        rows, cols, n_lvl, s_tokens, le_dtype = ctx.dims
+        gq = gq.contiguous()
+        g_le = None
+        if ctx.needs_input_grad[2]:
+            partials = torch.empty((POS_QUERY_PARTIAL_ROWS, n_lvl, cols), dtype=torch.float32, device=gq.device)
+            with torch.cuda.device(gq.device):
+                rc = lib.transoar_pos_query_backward(gq.data_ptr(), level_start.data_ptr(), n_lvl, s_tokens,
+                                                     partials.data_ptr(), rows, cols,
+                                                     torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError("transoar_pos_query_backward failed with code %d" % rc)
+            g_le = partials.sum(0).to(le_dtype)
+        return gq, None, g_le, None           # d q / d x = 1: the query's gradient IS the tokens' gradient
+
+
+def pos_query(x16, pos_sine, level_embed, level_start):
+    """bf16(x16 + (pos_sine[s] + level_embed[level(s)])) for contiguous bf16 tokens (..., S, C) in one pass; the
+    backward hands the query's gradient on unchanged and reduces it per level for level_embed."""
+    return _PosQuery.apply(x16, pos_sine, level_embed, level_start)
 
 
 class _ReluDropout(torch.autograd.Function):
