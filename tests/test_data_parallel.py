@@ -117,3 +117,40 @@ def test_single_process_reducer_is_a_noop():
     lin(torch.ones(2, 4)).sum().backward()
     r.finish()
     assert lin.weight.grad is not None
+
+
+def _compress_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transoar_amd.data_parallel import GradientAllReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Tanh(), torch.nn.Linear(96, 8))
+    x = torch.randn(2, 16, 64)
+    out = {}
+    for mode in (None, "bf16"):
+        red = GradientAllReducer(net, bucket_bytes=2 << 10, compress=mode)
+        assert red.active and len(red.buckets) >= 2 and all((b.wire is not None) == (mode == "bf16") for b in red.buckets)
+        for _ in range(2):                      # second pass: after the first-step bookkeeping
+            red.begin()
+            net(x[rank]).square().sum().backward()
+            red.finish()
+        out[mode] = [p.grad.clone() for p in net.parameters()]
+        red.remove()
+        for p in net.parameters():
+            p.grad = None
+    if rank == 0:
+        torch.save(out, out_path)
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_compression_sums_rounded_gradients():
+    """compress="bf16": the exchanged sum equals the fp32 exchange up to the bf16 rounding of each rank's gradient."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "out.pt")
+        port = 31500 + (os.getpid() % 2000)
+        mp.spawn(_compress_worker, args=(2, port, out_path), nprocs=2, join=True)
+        res = torch.load(out_path)
+    for g32, g16 in zip(res[None], res["bf16"]):
+        assert g16.dtype == torch.float32
+        assert (g16 - g32).abs().max().item() <= 2.0 ** -7 * g32.abs().max().item()
+        assert not torch.equal(g16, g32) or g32.abs().max().item() == 0.0

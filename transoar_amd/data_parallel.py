@@ -21,7 +21,13 @@ messages, launched early):
     exchange of the big early buckets (encoder stage 5: 96 MB) hides behind the
     expensive full-resolution backbone backward that is still to run;
   * parameters that never receive a gradient (the dead ``cross_attn.q_proj``,
-    SURVEY F8) are discovered in the first step and excluded afterwards.
+    SURVEY F8) are discovered in the first step and excluded afterwards;
+  * optional wire compression (``compress="bf16"`` / TRANSOAR_DP_COMPRESS=bf16):
+    a bucket travels as a bf16 copy (half the bytes per xGMI link: 108 instead
+    of 217 MB per step) and is widened back into the fp32 bucket after the
+    wait; the sum over ranks is then a sum of bf16-rounded gradients (2^-9
+    relative per element and rank).  Off by default: the step is not
+    exchange-bound on the estimates of DESIGN.md section 6.
 """
 import os
 
@@ -30,10 +36,12 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    def __init__(self, params, device, dtype):
+    def __init__(self, params, device, dtype, wire_dtype=None):
         self.params = params
         total = sum(p.numel() for p in params)
         self.flat = torch.zeros(total, device=device, dtype=dtype)
+        # what the collective moves: the bucket itself, or its rounded copy
+        self.wire = None if wire_dtype in (None, dtype) else torch.zeros(total, device=device, dtype=wire_dtype)
         self.views, off = [], 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -44,9 +52,15 @@ class _Bucket:
 
 
 class GradientAllReducer:
-    def __init__(self, module, process_group=None, bucket_bytes=48 << 20, always_flat=False):
+    def __init__(self, module, process_group=None, bucket_bytes=48 << 20, always_flat=False, compress=None):
         """always_flat: build the flat gradient buckets even for one rank (the captured-graph
-        training step needs gradients at fixed addresses that can be zeroed with a few memsets)."""
+        training step needs gradients at fixed addresses that can be zeroed with a few memsets).
+        compress: None (fp32 on the wire) or "bf16"; default from TRANSOAR_DP_COMPRESS."""
+        if compress is None:
+            compress = os.environ.get("TRANSOAR_DP_COMPRESS") or None
+        if compress not in (None, "bf16"):
+            raise ValueError("GradientAllReducer: compress must be None or 'bf16', got %r" % (compress,))
+        self.wire_dtype = torch.bfloat16 if compress == "bf16" else None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("TRANSOAR_FORCE_DP")))
@@ -73,7 +87,7 @@ class GradientAllReducer:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _add_bucket(self, params):
-        b = _Bucket(list(params), params[0].device, params[0].dtype)
+        b = _Bucket(list(params), params[0].device, params[0].dtype, self.wire_dtype if self.active else None)
         for p, v in zip(b.params, b.views):
             self._bucket_of[p] = b
             p.grad = v
@@ -109,7 +123,13 @@ class GradientAllReducer:
             self._fired.add(p)
         b.pending -= 1
         if b.pending == 0 and self.overlap and self.active:
-            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.handle = self._launch(b)
+
+    def _launch(self, b):
+        if b.wire is not None:
+            b.wire.copy_(b.flat)
+        return dist.all_reduce(b.flat if b.wire is None else b.wire, op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=True)
 
     def finish(self):
         """Call after backward, before the optimizer: wait for every bucket."""
@@ -121,9 +141,11 @@ class GradientAllReducer:
                 b.handle = None
         for b in self.buckets:
             if b.handle is None:     # first step only: a parameter without gradient held it back
-                b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.handle = self._launch(b)
         for b in self.buckets:
             b.handle.wait()
+            if b.wire is not None:
+                b.flat.copy_(b.wire)
         self._end_first_step()
 
     def _end_first_step(self):
