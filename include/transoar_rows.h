@@ -11,7 +11,8 @@
 extern "C" {
 #endif
 
-/* out[b][k][:] = src[b][index[k]][:]   src (B,S,row) out (B,K,row), index int32 (K) */
+/* out[b][k][:] = src[b][index[k]][:]   src (B,S,row) out (B,K,row), index int32 (K).  S is only the distance between
+ * batch elements in rows: a row-dense slice of a larger (B, S_total, row) matrix is read in place with S = S_total. */
 int transoar_rows_gather(const void* src, const int* index, void* out, int B, long S, long K,
                          int row_bytes, void* hip_stream);
 

@@ -16,6 +16,13 @@ def test_rows_gather_and_pull_sum(dtype):
     index = torch.randint(0, S, (K,), generator=g)
     out = rows.gather(x, index.int().cuda())
     assert torch.equal(out, x[:, index.cuda()])
+    # one level cut out of a larger token matrix: read in place (batch stride = the matrix's rows), no copy
+    big = torch.randn(B, S + 77, C, generator=g).to(dtype).cuda()
+    level = big[:, 40:40 + S]
+    assert rows.row_dense(level) and not level.is_contiguous()
+    assert torch.equal(rows.gather(level, index.int().cuda()), level[:, index.cuda()])
+    assert torch.equal(rows.gather(big[:, :S:2], index.int().cuda()[:10] // 2),
+                       big[:, :S:2][:, (index[:10] // 2).cuda()])          # not row-dense: falls back to a copy
     # CSR inverse
     order = torch.argsort(index, stable=True)
     counts = torch.bincount(index, minlength=S)

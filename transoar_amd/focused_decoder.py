@@ -148,7 +148,8 @@ class FocusedAttn(nn.Module):
 
     def _roi_tokens(self, v, k_pos, flat, inverse):
         """-> (gathered value tokens (B, O*L, C), key tokens = value tokens + gathered positions)"""
-        v_tok = _GatherTokens.apply(v.contiguous(), flat, inverse)         # (B, O*L, C)
+        # a level cut out of the pyramid's token matrix is read in place (rows.row_dense): no 157-MB copy
+        v_tok = _GatherTokens.apply(v if (rows.usable(v) and rows.row_dense(v)) else v.contiguous(), flat, inverse)         # (B, O*L, C)
         if k_pos is None:
             k_tok = v_tok
         elif rows.usable(k_pos) and k_pos.is_contiguous():

@@ -44,9 +44,21 @@ def usable(x):
             and (x.shape[2] * x.element_size()) % 16 == 0)
 
 
+def row_dense(x):
+    """(B, S, C) whose rows are dense and whose batch stride is a whole number of rows: a contiguous tensor, or one
+    level cut out of the (N, S_total, C) pyramid -- what the gather kernel can read in place."""
+    return (x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2]
+            and (x.shape[0] == 1 or (x.stride(0) % x.shape[2] == 0 and x.stride(0) >= x.shape[1] * x.shape[2]))
+            and x.data_ptr() % 16 == 0)
+
+
 def gather(x, index):
-    """x (B,S,C) contiguous, index int32 (K,) -> (B,K,C)"""
+    """x (B,S,C) row-dense (see row_dense: the batch stride is passed as the kernel's S), index int32 (K,) -> (B,K,C)"""
+    if not row_dense(x):
+        x = x.contiguous()
     b, s, c = x.shape
+    if b > 1:
+        s = x.stride(0) // c            # rows between batch elements
     k = index.numel()
     out = torch.empty((b, k, c), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
