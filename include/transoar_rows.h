@@ -27,6 +27,11 @@ int transoar_rows_pull_sum(const void* g, const int* inv_ptr, const int* inv_idx
 int transoar_rows_colsum(const void* x, float* out, float* workspace, long rows, int cols, void* hip_stream);
 int transoar_rows_colsum_workspace_floats(int cols);
 
+/* The same sum for SHORT matrices in one launch (a workgroup per 16-byte column group walks all rows): x (rows, cols)
+ * bf16 (cols % 8 == 0) or fp32 (cols % 4 == 0), out (cols) fp32.  For the 10^3-row bias gradients of the Focused
+ * Decoder's linears (necks/focused_decoder.py:12-59) and the per-wave partial sums of the token kernels. */
+int transoar_rows_colsum_small(const void* x, float* out, long rows, int cols, int is_bf16, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

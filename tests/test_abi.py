@@ -135,6 +135,11 @@ def test_sampling_head_and_colsum_argument_errors():
     assert c(None, p16, p16, 8, 8, None) == -1
     assert c(p16, p16, p16, 8, 12, None) == -2                             # cols not a multiple of 8
     assert rows.transoar_rows_colsum_workspace_floats(384) == 1024 * 384
+    cs = rows.transoar_rows_colsum_small
+    cs.argtypes = [p, p, lg, i, i, p]
+    assert cs(None, p16, 8, 8, 1, None) == -1
+    assert cs(p16, p16, 8, 12, 1, None) == -2                              # bf16: cols not a multiple of 8
+    assert cs(p16, p16, 8, 6, 0, None) == -2                               # fp32: cols not a multiple of 4
 
 
 def test_convgemm_and_fused_gather_argument_errors():

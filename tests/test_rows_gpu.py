@@ -49,3 +49,26 @@ def test_colsum_matches_fp32_sum(shape):
     bound = 1e-5 * x.double().abs().sum(0)
     assert got.dtype == torch.float32 and got.shape == (shape[1],)
     assert bool(((got.double() - ref).abs() <= bound + 1e-6).all())
+
+
+@pytest.mark.parametrize("shape,dtype", [((1080, 384), torch.bfloat16), ((1080, 1024), torch.bfloat16),
+                                         ((3240, 384), torch.bfloat16), ((7, 8), torch.bfloat16),
+                                         ((1025, 2048), torch.bfloat16), ((4096, 2304), torch.float32),
+                                         ((1024, 1536), torch.float32), ((300, 12), torch.float32),
+                                         ((1, 4), torch.float32), ((20000, 96), torch.float32)])
+def test_colsum_small_matches_fp32_sum(shape, dtype):
+    """One-launch column sums of short matrices (Focused Decoder bias gradients, per-wave partials of the token kernels)."""
+    from transoar_amd import rows
+    torch.manual_seed(shape[0])
+    x = torch.randn(shape, device="cuda").to(dtype)
+    assert rows.colsum_small_usable(x)
+    got = rows.colsum_small(x)
+    ref = x.double().sum(0)
+    bound = 1e-5 * x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (shape[1],)
+    assert bool(((got.double() - ref).abs() <= bound + 1e-6).all())
+    # the dispatcher: same numbers whichever kernel it picks; torch for what neither kernel takes
+    any_ = rows.colsum_any(x)
+    assert bool(((any_.double() - ref).abs() <= bound + 1e-6).all())
+    odd = torch.randn(33, 10, device="cuda")
+    assert torch.allclose(rows.colsum_any(odd), odd.sum(0))

@@ -67,6 +67,58 @@ __global__ __launch_bounds__(256) void rows_pull_sum(const u32x4r* __restrict__ 
   out[(b * S + s) * vec_per_row + v] = o;
 }
 
+// Column sums of a SHORT matrix (hundreds to a few thousand rows: the bias gradients of the Focused Decoder's
+// 1080-row linears, the per-wave partials of the token kernels) in ONE launch: a workgroup owns one 16-byte column
+// group (8 bf16 / 4 fp32 columns) and walks all rows, 256 at a time, four loads in flight per thread; the 256 row lanes
+// meet in LDS.  The 16-byte pieces of a wave are a row pitch apart, but the neighbouring column groups' workgroups
+// read the rest of the same lines at the same time: the matrix (<= a few MB) is served by L2.  torch's reduce kernel
+// needs 13-25 us for these shapes (two passes, 64-byte accesses); this one is latency of ~(rows / 1024) load rounds.
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_small(const u32x4r* __restrict__ x, float* __restrict__ out, long rows,
+                                                    int vec_per_row) {
+  constexpr int NE = BF16 ? 8 : 4;
+  __shared__ float red[256][NE + 1];
+  const int v = blockIdx.x;
+  float acc[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) acc[e] = 0.f;
+  auto add = [&](const u32x4r& q) {
+    if (BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += __uint_as_float(q[e] << 16);
+        acc[2 * e + 1] += __uint_as_float(q[e] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += __uint_as_float(q[e]);
+    }
+  };
+  long r = threadIdx.x;
+  for (; r + 768 < rows; r += 1024) {
+    const u32x4r q0 = x[r * vec_per_row + v], q1 = x[(r + 256) * vec_per_row + v];
+    const u32x4r q2 = x[(r + 512) * vec_per_row + v], q3 = x[(r + 768) * vec_per_row + v];
+    add(q0); add(q1); add(q2); add(q3);
+  }
+  for (; r < rows; r += 256) add(x[r * vec_per_row + v]);
+#pragma unroll
+  for (int e = 0; e < NE; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  for (int half = 128; half >= NE; half >>= 1) {          // tree over the row lanes, down to NE rows
+    if (static_cast<int>(threadIdx.x) < half) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) red[threadIdx.x][e] += red[threadIdx.x + half][e];
+    }
+    __syncthreads();
+  }
+  if (static_cast<int>(threadIdx.x) < NE) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) t += red[k][threadIdx.x];
+    out[static_cast<long>(v) * NE + threadIdx.x] = t;
+  }
+}
+
 // Column sums of a bf16 (rows, cols) matrix in fp32: the bias gradients of the token projections and of the FPN
 // output convolutions (channels-last: rows = voxels).  Pass 1: kColsumBlocks workgroups, a thread owns one 16-byte
 // column group and every (blocks * R)-th row, the R row lanes of a workgroup meet in LDS; pass 2 adds the
@@ -164,6 +216,20 @@ extern "C" int transoar_rows_pull_sum(const void* g, const int* inv_ptr, const i
   else
     hipLaunchKernelGGL(rows_pull_sum<false>, grid, dim3(256), 0, st, static_cast<const u32x4r*>(g), inv_ptr, inv_idx,
                        static_cast<u32x4r*>(out), S, K, vpr);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_rows_colsum_small(const void* x, float* out, long rows, int cols, int is_bf16, void* hip_stream) {
+  using namespace transoar;
+  if (!x || !out) return -1;
+  const int per = is_bf16 ? 8 : 4;
+  if (rows <= 0 || cols <= 0 || (cols % per) || rows > (1L << 20)) return -2;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int vpr = cols / per;
+  if (is_bf16)
+    hipLaunchKernelGGL(colsum_small<true>, dim3(vpr), dim3(256), 0, st, static_cast<const u32x4r*>(x), out, rows, vpr);
+  else
+    hipLaunchKernelGGL(colsum_small<false>, dim3(vpr), dim3(256), 0, st, static_cast<const u32x4r*>(x), out, rows, vpr);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -19,6 +19,8 @@ lib.transoar_rows_colsum.restype = _i
 lib.transoar_rows_colsum.argtypes = [_p, _p, _p, _l, _i, _p]
 lib.transoar_rows_colsum_workspace_floats.restype = _i
 lib.transoar_rows_colsum_workspace_floats.argtypes = [_i]
+lib.transoar_rows_colsum_small.restype = _i
+lib.transoar_rows_colsum_small.argtypes = [_p, _p, _l, _i, _i, _p]
 
 
 def colsum_usable(x):
@@ -37,6 +39,33 @@ def colsum(x):
     if rc:
         raise RuntimeError("transoar_rows_colsum failed with code %d" % rc)
     return out
+
+
+def colsum_small_usable(x):
+    return (x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0 and 0 < x.shape[0] <= 65536
+            and ((x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0) or (x.dtype == torch.float32 and x.shape[1] % 4 == 0)))
+
+
+def colsum_small(x):
+    """x (rows, cols) bf16 / fp32 contiguous, a short matrix -> (cols,) fp32 column sums in one launch."""
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_rows_colsum_small(x.data_ptr(), out.data_ptr(), rows, cols, int(x.dtype == torch.bfloat16),
+                                            torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise RuntimeError("transoar_rows_colsum_small failed with code %d" % rc)
+    return out
+
+
+def colsum_any(x):
+    """x.sum(0, dtype=float32) of a 2-D tensor on the kernel that fits its height (two-pass for >= 4096 bf16 rows, the
+    one-launch kernel for short matrices and fp32 partials), torch's reduction otherwise."""
+    if colsum_usable(x):
+        return colsum(x)
+    if colsum_small_usable(x):
+        return colsum_small(x)
+    return x.sum(0, dtype=torch.float32)
 
 
 def usable(x):

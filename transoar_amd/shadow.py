@@ -22,6 +22,8 @@ gradients.  (The weight gradient is rounded to bf16 by autocast's path before it
 import torch
 import torch.nn.functional as F
 
+from . import rows
+
 _ALIGN = 64          # elements: 128 bytes of bf16
 _current = None      # the registry whose mirrors are fresh: set by `fresh()` around a forward pass
 
@@ -145,7 +147,7 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = torch.mm(gy2.t(), xb.reshape(-1, xb.shape[-1]), out_dtype=torch.float32)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = gy2.sum(0, dtype=torch.float32)
+                gb = rows.colsum_any(gy2)
         return gx, gw, gb, None, None
 
 
@@ -211,7 +213,7 @@ class _SelfAttnProj(torch.autograd.Function):
             gxv = (g2 @ wb[2 * c:]).view(xv.shape).to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None
             gw = torch.cat((torch.mm(g1.t(), xq.reshape(-1, c), out_dtype=torch.float32),
                             torch.mm(g2.t(), xv.reshape(-1, c), out_dtype=torch.float32)))
-            gb = torch.cat((g1.sum(0, dtype=torch.float32), g2.sum(0, dtype=torch.float32)))
+            gb = torch.cat((rows.colsum_any(g1), rows.colsum_any(g2)))
         return gxq, gxv, gw, gb, None, None
 
 

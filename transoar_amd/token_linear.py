@@ -112,7 +112,7 @@ class _TokenLinear(torch.autograd.Function):
             if ctx.needs_input_grad[1] or (ctx.split is not None and ctx.needs_input_grad[4]):
                 gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = rows.colsum(gy2) if rows.colsum_usable(gy2) else gy2.sum(0, dtype=torch.float32)
+                gb = rows.colsum_any(gy2)
         if ctx.split is not None and gw is not None:
             return gx, gw[:ctx.split], gb, None, gw[ctx.split:]
         return gx, gw, gb, None, None
