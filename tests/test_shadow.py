@@ -125,3 +125,38 @@ def test_folded_attention_keeps_fp32_weights_outside_autocast(follow):
     p = (qq @ kk.transpose(-2, -1)).masked_fill(pad[None, :, None, None, :], float("-inf")).softmax(-1)
     want = (p @ vv).permute(0, 1, 3, 2, 4).reshape(b, n_org * qpo, c)
     assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_focused_decoder_add_norm_on_the_fused_kernel():
+    """FocusedDecoderLayer._add_norm: norm(x + branch) of the decoder sub-layers on csrc/tokens.hip against the eager
+    chain under bf16 autocast (fp32 stream + bf16 branch), values and gradients."""
+    from transoar_amd.focused_decoder import FocusedDecoderLayer
+    torch.manual_seed(5)
+    dev = "cuda"
+    norm = torch.nn.LayerNorm(384).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.3, 0.3)
+    drop = torch.nn.Dropout(0.1).eval()
+    x0 = torch.randn(2, 540, 384, device=dev)
+    r0 = torch.randn(2, 540, 384, device=dev).to(torch.bfloat16)
+    g32 = torch.randn(2, 540, 384, device=dev)
+    g16 = torch.randn(2, 540, 384, device=dev).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        FocusedDecoderLayer.fused_norms = fused
+        try:
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            norm.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y32, y16 = FocusedDecoderLayer._add_norm(None, x.expand(2, 540, 384), r, norm, drop)
+                assert (y16 is not None) == fused and y32.dtype == torch.float32
+                y16 = y32.to(torch.bfloat16) if y16 is None else y16
+            ((y32 * g32).sum() + (y16.float() * g16.float()).sum()).backward()
+            res[fused] = (y32.detach(), y16.detach().float(), x.grad, r.grad.float(), norm.weight.grad.clone(),
+                          norm.bias.grad.clone())
+        finally:
+            FocusedDecoderLayer.fused_norms = True
+    for name, a, b in zip(("y32", "y16", "gx", "gr", "gw", "gb"), res[True], res[False]):
+        tol = 2e-2 if name in ("gr", "y16") else 2e-4         # rounded to bf16 on both routes: one ulp apart at most
+        assert (a - b).abs().max().item() <= tol * b.abs().max().item(), name

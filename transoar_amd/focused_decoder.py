@@ -31,6 +31,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import rows, shadow
+from . import tokens as fused_tokens
 from .position_encoding import is_constant
 from .token_linear import token_linear
 
@@ -382,17 +383,35 @@ class FocusedDecoderLayer(nn.Module):
         if sa is None:
             sa = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                                 need_weights=False)[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(sa))
+        tgt, _ = self._add_norm(tgt, sa, self.norm2, self.dropout2)
 
         q = tgt if query_pos is None else tgt + query_pos
         roi = (self.roi_index, self.roi_pad, self.roi_inv_ptr, self.roi_inv_idx) if self._use_roi else None
         ca, weights = self.cross_attn(q, None if src_pos is not None else src, src, mask=self._dense_bias,
                                       need_weights=need_weights, roi=roi, k_pos=src_pos, roi_cache=roi_cache)
-        tgt = self.norm1(tgt + self.dropout1(ca))
+        tgt, tgt16 = self._add_norm(tgt, ca, self.norm1, self.dropout1)
 
-        hidden = self.activation(shadow.linear(tgt, self.linear1.weight, self.linear1.bias))
+        # the fused pass also returns the bf16 rounding the FFN's first GEMM would make of tgt
+        hidden = self.activation(shadow.linear(tgt if tgt16 is None else tgt16, self.linear1.weight, self.linear1.bias))
         ffn = shadow.linear(self.dropout3(hidden), self.linear2.weight, self.linear2.bias)
-        return self.norm3(tgt + self.dropout4(ffn)), weights
+        return self._add_norm(tgt, ffn, self.norm3, self.dropout4)[0], weights
+
+    # norm(x + dropout(branch)) of the three sub-layers on the fused token kernel of the refine block (csrc/tokens.hip:
+    # one pass each way, dropout inside).  The eager chain adds an fp32 stream and a bf16 branch with torch's
+    # mixed-dtype element-wise kernel -- ~40 us per [2, 540, 384] add on this build, 9 of them per step -- before
+    # layer_norm and after dropout.  TRANSOAR_FD_STOCK_NORMS=1 keeps the chain.
+    fused_norms = os.environ.get("TRANSOAR_FD_STOCK_NORMS") is None
+
+    def _add_norm(self, x, branch, norm, dropout):
+        """-> (norm(x + dropout(branch)) in fp32, its bf16 rounding or None)"""
+        if (FocusedDecoderLayer.fused_norms and x.is_cuda and x.dtype == torch.float32 and branch.dtype == torch.bfloat16
+                and branch.shape == x.shape and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+            xc, rc = x.contiguous(), branch.contiguous()
+            if fused_tokens.usable(xc, rc, x.shape[-1]):
+                y32, y16, _ = fused_tokens.add_layernorm(xc, rc, norm, dropout=dropout)
+                return y32, y16
+        return norm(x + dropout(branch)), None
 
 
 class FocusedDecoderModel(nn.Module):
