@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _native  # noqa: F401
-from . import rows
+from . import rows as _rows
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_tokens.so")
@@ -127,7 +127,7 @@ class _AddLayerNorm(torch.autograd.Function):
                 torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_add_layernorm_backward failed with code %d" % rc)
-        sums = rows.colsum_any(partials.view(PARTIAL_ROWS, -1)).view(2 + n_lvl, cols)     # one launch (rows.colsum_small)
+        sums = _rows.colsum_any(partials.view(PARTIAL_ROWS, -1)).view(2 + n_lvl, cols)     # one launch (rows.colsum_small)
         g_le = None
         if ctx.with_q and ctx.needs_input_grad[6]:
             g_le = (sums[2:] if n_lvl else torch.zeros(ctx.n_lvl, cols, device=x.device)).to(ctx.le_dtype)
@@ -215,7 +215,7 @@ class _PosQuery(torch.autograd.Function):
                                                      torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 raise RuntimeError("transoar_pos_query_backward failed with code %d" % rc)
-            g_le = rows.colsum_any(partials.view(POS_QUERY_PARTIAL_ROWS, -1)).view(n_lvl, cols).to(le_dtype)
+            g_le = _rows.colsum_any(partials.view(POS_QUERY_PARTIAL_ROWS, -1)).view(n_lvl, cols).to(le_dtype)
         return gq, None, g_le, None           # d q / d x = 1: the query's gradient IS the tokens' gradient
 
 
