@@ -84,6 +84,34 @@ def test_reference_checkpoint_dict_round_trip(tmp_path):
     assert s1.keys() == s2.keys() and all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1)
 
 
+def test_tensor_learning_rates_are_saved_and_loaded_as_floats(tmp_path):
+    """Round-3 ADVICE: the capturable AdamW of TrainStep(graph=True) keeps lr / initial_lr as tensors.  A checkpoint
+    written from it holds Python floats (the reference Trainer's format), and a state dict that does carry tensor
+    rates (an older file) still loads into an optimizer with float rates and steps."""
+    from transoar_amd.checkpoint import build_scheduler, load_checkpoint, load_optimizer_state, save_checkpoint
+    lin = torch.nn.Linear(4, 3)
+    opt = torch.optim.AdamW([{"params": [lin.weight], "lr": torch.tensor(2e-5)}, {"params": [lin.bias], "lr": torch.tensor(2e-4)}],
+                            weight_decay=1e-4, foreach=False, capturable=False)
+    for g in opt.param_groups:
+        g["initial_lr"] = torch.tensor(float(g["lr"]))
+    sched = build_scheduler(opt, {"lr_drop": 5})
+    lin.weight.grad, lin.bias.grad = torch.ones_like(lin.weight), torch.ones_like(lin.bias)
+    path = tmp_path / "ckpt.pt"
+    save_checkpoint(path, lin, opt, sched, epoch=1)
+    raw = torch.load(path, weights_only=False)["optimizer_state_dict"]["param_groups"]
+    assert all(isinstance(g["lr"], float) and isinstance(g["initial_lr"], float) for g in raw)
+    assert [round(g["lr"], 9) for g in raw] == [2e-5, 2e-4]
+    # an eager optimizer with float rates takes both the portable file and a raw tensor-rate state dict
+    lin2 = torch.nn.Linear(4, 3)
+    opt2 = torch.optim.AdamW([{"params": [lin2.weight], "lr": 1.0}, {"params": [lin2.bias], "lr": 1.0}], weight_decay=1e-4, foreach=True)
+    load_checkpoint(path, lin2, opt2)
+    assert [g["lr"] for g in opt2.param_groups] == pytest.approx([2e-5, 2e-4])
+    load_optimizer_state(opt2, opt.state_dict())
+    assert all(isinstance(g["lr"], float) for g in opt2.param_groups)
+    lin2.weight.grad, lin2.bias.grad = torch.ones_like(lin2.weight), torch.ones_like(lin2.bias)
+    opt2.step()          # foreach AdamW raises on tensor rates with capturable=False
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
 def test_reference_yaml_files_build_models_with_the_reference_keys(golden_dir):
     """Container only: the reference's own experiment files load through load_config (with a synthetic

@@ -33,9 +33,8 @@ CASES = [  # N, Cin, Cout, D, H, W, stride, bias
 def test_conv3d_k3_forward_backward(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from transoar_amd.conv3d import Conv3dK3, _Conv3dK3
+    from transoar_amd.conv3d import Conv3dK3
     Conv3dK3.min_voxels = 0                 # small shapes on purpose: always take the HIP path
-    _Conv3dK3.hip_wgrad = _Conv3dK3.hip_dgrad_strided = True
     n, ci, co, d, h, w, s, bias = case
     torch.manual_seed(ci * 1000 + co)
     conv = Conv3dK3(ci, co, 3, stride=s, padding=1, bias=bias).cuda()
@@ -83,13 +82,15 @@ def _gpu_relerr(a, b):
                                   (2, 24, 48, 160, 160, 256, 2), (2, 48, 48, 80, 80, 128, 1), (2, 48, 96, 80, 80, 128, 2),
                                   (2, 96, 96, 40, 40, 64, 1), (2, 96, 192, 40, 40, 64, 2), (2, 192, 384, 20, 20, 32, 2),
                                   (2, 384, 384, 10, 10, 16, 1), (2, 384, 768, 10, 10, 16, 2), (2, 768, 768, 5, 5, 8, 1),
-                                  (2, 96, 384, 40, 40, 64, 1), (2, 384, 384, 5, 5, 8, 1)])
+                                  (2, 96, 384, 40, 40, 64, 1), (2, 384, 384, 5, 5, 8, 1),
+                                  # AMOS geometry at its reference batch (round-3 ADVICE): 2 x 128 x 128 x 64 = 2^21 output
+                                  # rows, one more than an implicit-GEMM launch addresses -> batch ranges (conv_gemm._batch_chunks)
+                                  (2, 24, 48, 256, 256, 128, 2), (2, 48, 48, 128, 128, 64, 1)])
 def test_conv3d_k3_flagship_layer_shapes(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from transoar_amd.conv3d import Conv3dK3, _Conv3dK3
+    from transoar_amd.conv3d import Conv3dK3
     Conv3dK3.min_voxels = 0
-    _Conv3dK3.hip_wgrad, _Conv3dK3.hip_dgrad_strided = False, False      # class defaults
     n, ci, co, d, h, w, s = case
     torch.manual_seed(ci + co)
     conv = Conv3dK3(ci, co, 3, stride=s, padding=1, bias=False).cuda()

@@ -3,10 +3,15 @@ no hipify: the sources are HIP written for CDNA4 and compiled as-is).
 
     python transoar_amd/_build.py [--force]   # run by PATH: importing the package
                                               # would load the (possibly stale) .so
+
+A library is rebuilt when one of the files it includes (hipcc's own depfile of
+the last build, kept next to the .so as `.<name>.d`) is newer than it; the
+stale libraries are compiled in parallel.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
@@ -26,13 +31,27 @@ LIBS = {
 }
 
 
-def _deps():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
-        os.path.join(PKG, "..", "include", f) for f in os.listdir(os.path.join(PKG, "..", "include"))]
-
-
 def lib_path(name):
     return os.path.join(PKG, name)
+
+
+def _dep_path(name):
+    return os.path.join(PKG, "." + name + ".d")
+
+
+def _deps(name):
+    """Files the library was built from: the depfile of its last build (project files only), or, without
+    one, every file of csrc/ and include/."""
+    try:
+        with open(_dep_path(name)) as f:
+            words = f.read().replace("\\\n", " ").split()
+        deps = [w for w in words[1:] if not w.startswith("/opt/") and not w.startswith("/usr/")]
+        if deps:
+            return deps + [os.path.join(CSRC, s) for s in LIBS[name]]
+    except OSError:
+        pass
+    inc = os.path.join(PKG, "..", "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
 
 
 def is_stale(name):
@@ -40,21 +59,32 @@ def is_stale(name):
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    for d in _deps(name):
+        try:
+            if os.path.getmtime(d) > t:
+                return True
+        except OSError:          # a file of the last build is gone
+            return True
+    return False
 
 
-def build(force=False, verbose=True):
+def _compile(name, verbose):
+    cmd = [HIPCC] + COMMON_FLAGS + [os.path.join(CSRC, s) for s in LIBS[name]] + ["-o", lib_path(name)]
+    if len(LIBS[name]) == 1:
+        cmd += ["-MD", "-MF", _dep_path(name)]
+    if verbose:
+        print("[transoar_amd] " + " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return name
+
+
+def build(force=False, verbose=True, only=None):
     """Compile every stale library.  Cross-compiles without a GPU."""
-    built = []
-    for name, srcs in LIBS.items():
-        if not (force or is_stale(name)):
-            continue
-        cmd = [HIPCC] + COMMON_FLAGS + [os.path.join(CSRC, s) for s in srcs] + ["-o", lib_path(name)]
-        if verbose:
-            print("[transoar_amd] " + " ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        built.append(name)
-    return built
+    names = [n for n in LIBS if (only is None or n in only) and (force or is_stale(n))]
+    if not names:
+        return []
+    with ThreadPoolExecutor(max_workers=min(len(names), os.cpu_count() or 4)) as pool:
+        return list(pool.map(lambda n: _compile(n, verbose), names))
 
 
 if __name__ == "__main__":

@@ -59,12 +59,27 @@ def build_scheduler(optimizer, config):
     return torch.optim.lr_scheduler.StepLR(optimizer, int(config["lr_drop"]))
 
 
+def _portable_optimizer_state(optimizer):
+    """optimizer.state_dict() in the reference Trainer's format (trainer.py:230-241): Python-float learning rates.  The
+    capturable AdamW of TrainStep(graph=True) keeps `lr` / `initial_lr` as device tensors; written as they are, the file
+    would not load into a non-capturable optimizer (eager mode, CPU, the reference's own AdamW)."""
+    state = optimizer.state_dict()
+    groups = []
+    for g in state["param_groups"]:
+        g = dict(g)
+        for k in ("lr", "initial_lr"):
+            if torch.is_tensor(g.get(k)):
+                g[k] = float(g[k])
+        groups.append(g)
+    return {"state": state["state"], "param_groups": groups}
+
+
 def save_checkpoint(path, model, optimizer, scheduler, epoch, metric_max_val=0.0):
     torch.save({
         "epoch": epoch,
         "metric_max_val": metric_max_val,
         "model_state_dict": model.state_dict(),
-        "optimizer_state_dict": optimizer.state_dict(),
+        "optimizer_state_dict": _portable_optimizer_state(optimizer),
         "scheduler_state_dict": scheduler.state_dict(),
     }, path)
 
@@ -90,6 +105,10 @@ def load_optimizer_state(optimizer, state_dict):
             loaded = g["lr"]
             b["lr"].fill_(float(loaded))
             g["lr"] = b["lr"]
+        elif torch.is_tensor(g["lr"]):
+            # the other direction (round-3 ADVICE): a checkpoint written by the capturable optimizer, loaded into one
+            # with Python-float rates -- foreach AdamW refuses tensor rates, fused AdamW wants them on its own device
+            g["lr"] = float(g["lr"])
         if "initial_lr" in g and torch.is_tensor(g["initial_lr"]):
             g["initial_lr"] = float(g["initial_lr"])
     for p, st in optimizer.state.items():

@@ -267,55 +267,32 @@ class _Conv3dK3(torch.autograd.Function):
         ctx.stride, ctx.has_bias = stride, bias is not None
         return y
 
-    # which parts of the backward run on the hand-written kernels (measured per layer in
-    # tools/bench_conv.py, profiles/r01_conv_layers.jsonl): the stride-1 data gradient always; the
-    # dilated (stride-2) data gradient and the weight gradient only when switched on -- their v1
-    # kernels lose to MIOpen's tuned implicit GEMM, which is used through aten otherwise.
-    hip_dgrad_strided = False
-    hip_wgrad = False
-    miopen_ndhwc = os.environ.get("TRANSOAR_MIOPEN_NDHWC", "1") == "1"
-
     @staticmethod
     def backward(ctx, gy):
+        # Every gradient runs on a hand-written kernel; there is no stock (MIOpen) branch.  A problem no kernel
+        # covers raises: falling through to MIOpen's untuned 3-D bf16 kernels once cost a 1.7-second step.
         xb, weight, wkt = ctx.saved_tensors
         gyb = _as_ndhwc(gy)
         gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gemm = _use_gemm(xb.shape[1], weight.shape[0], ctx.stride)
-        hip_x = need_x and (gemm or ctx.stride == 1 or _Conv3dK3.hip_dgrad_strided)
-        hip_w = need_w and _Conv3dK3.hip_wgrad
-        if hip_x and gemm:
+        ci, co = xb.shape[1], weight.shape[0]
+        if need_x and _use_gemm(ci, co, ctx.stride):
             gx = _cg.conv_dgrad(gyb, wkt if wkt is not None else _cg.pack_dgrad(weight), ctx.stride, tuple(xb.shape[2:]))
-        elif hip_x:
-            # data gradient = convolution of dy with the flipped, in/out-swapped filter
+        elif need_x:
+            # data gradient = convolution of dy with the flipped, in/out-swapped filter (stride 2: over the dilated dy)
             wt = weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(27, weight.shape[1], weight.shape[0])
             gx = conv3d_k3_forward(gyb, wt.to(torch.bfloat16).contiguous(), None, 1, dilated_input=ctx.stride == 2)
-        if need_w and ctx.stride == 1 and c1_wgrad_supported(xb, gyb):
-            gw, hip_w = conv3d_c1_wgrad(xb, gyb).to(weight.dtype), True       # one input channel: MFMA over voxel chunks
-        elif need_w and ctx.stride == 1 and lds_wgrad_supported(xb, gyb) and (max(xb.shape[1], gyb.shape[1]) <= 32 or gyb.numel() // gyb.shape[1] >= (1 << 21)):
-            gw, hip_w = conv3d_k3_wgrad_lds(xb, gyb).to(weight.dtype), True   # few channels, 10^7 voxels: LDS-transposed MFMA
-        elif need_w and xb.shape[1] % 8 == 0 and gyb.numel() // gyb.shape[1] < (1 << 21):
-            gw, hip_w = _cg.conv_wgrad(xb, gyb, ctx.stride).to(weight.dtype), True     # voxel-major GEMM with transposing LDS reads
-        elif hip_w:
-            gw = conv3d_k3_wgrad(xb, gyb, ctx.stride).to(weight.dtype)
-        if (need_x and not hip_x) or (need_w and not hip_w):
-            s = ctx.stride
-            # NCDHW-contiguous operands: that is the layout the tuned MIOpen find-db entries
-            # (miopen_db/) are keyed on; an NDHWC problem would fall back to MIOpen's naive kernels
-            # miopen_ndhwc: hand MIOpen the channels-last tensors as they are (its CK solvers are NDHWC
-            # natively; given NCDHW it transposes both operands internally on top of our own layout
-            # kernels -- 5 ms per step at stages 0-1).  Needs find-db entries tuned for the NDHWC keys.
-            if _Conv3dK3.miopen_ndhwc and xb.shape[1] > 1:
-                a_gy, a_x = gyb, xb
+        if need_w:
+            rows = gyb.numel() // gyb.shape[1]
+            if ctx.stride == 1 and c1_wgrad_supported(xb, gyb):
+                gw = conv3d_c1_wgrad(xb, gyb)             # one input channel: MFMA over voxel chunks
+            elif ctx.stride == 1 and lds_wgrad_supported(xb, gyb) and (max(ci, co) <= 32 or rows >= (1 << 21)):
+                gw = conv3d_k3_wgrad_lds(xb, gyb)         # few channels, 10^7 voxels: LDS-transposed MFMA
+            elif ci % 8 == 0 and co % 8 == 0:
+                gw = _cg.conv_wgrad(xb, gyb, ctx.stride)  # voxel-major GEMM with transposing LDS reads (batch ranges above 2^21 rows)
             else:
-                a_gy, a_x = to_ncdhw(gyb), to_ncdhw(xb)
-            ax, aw, _ = torch.ops.aten.convolution_backward(
-                a_gy, a_x, weight.to(torch.bfloat16), None, [s, s, s], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
-                [need_x and not hip_x, need_w and not hip_w, False])
-            if need_x and not hip_x:
-                gx = ax
-            if need_w and not hip_w:
-                gw = aw.to(weight.dtype)
+                gw = conv3d_k3_wgrad(xb, gyb, ctx.stride)  # channels-first shifted copies: any channel count (raises on what it cannot address)
+            gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g2 = gyb.permute(0, 2, 3, 4, 1).reshape(-1, gyb.shape[1])        # channels-last: a view, rows = voxels
             gb = _rows.colsum(g2) if _rows.colsum_usable(g2) else gyb.float().sum(dim=(0, 2, 3, 4))

@@ -165,11 +165,33 @@ def _igemm(x, wk, bias, out, src_dims, cin, cout, m_dims, src_stride, out_dims, 
                    "transoar_conv3d_igemm")
 
 
+MAX_ROWS = 1 << 21          # rows (voxels of the row space) per launch: the kernels decompose a row index with float reciprocals
+
+
+def _batch_chunks(n, rows_per_sample, what):
+    """Batch ranges [(first, count), ...] whose row count stays below MAX_ROWS (one range when the whole batch fits).
+    A channels-last (N, C, D, H, W) tensor sliced along N is still a dense channels-last tensor, so a range is just
+    another launch on a view.  AMOS at its reference batch (2 x 128 x 128 x 64 = 2^21 rows at stage 1) needs this."""
+    if n * rows_per_sample < MAX_ROWS:
+        return [(0, n)]
+    per = (MAX_ROWS - 1) // rows_per_sample
+    if per < 1:
+        raise RuntimeError("%s: one sample has %d rows, the implicit-GEMM kernels address < %d per launch"
+                           % (what, rows_per_sample, MAX_ROWS))
+    return [(i, min(per, n - i)) for i in range(0, n, per)]
+
+
 def conv_forward(x, wk, bias, stride, split=None):
     """x (N, Cin, D, H, W) NDHWC bf16, wk (27, Cout, Cin) bf16, bias fp32 or None -> (N, Cout, Do, Ho, Wo) NDHWC bf16."""
     n, ci, d, h, w = x.shape
     co = wk.shape[1]
     od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+    chunks = _batch_chunks(n, od * oh * ow, "conv_forward")
+    if len(chunks) > 1:
+        y = torch.empty((n, co, od, oh, ow), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
+        for i, c in chunks:
+            y[i:i + c] = conv_forward(x[i:i + c], wk, bias, stride, split)
+        return y
     y = torch.empty((n, co, od, oh, ow), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
     if split is None:
         split = _split_for(_tiles(n * od * oh * ow, co), (27 * ci + 63) // 64)
@@ -183,6 +205,12 @@ def conv_dgrad(gy, wkt, stride, in_dims, split=None):
     ci = wkt.shape[1]
     d, h, w = in_dims
     gx = torch.empty((n, ci, d, h, w), dtype=torch.bfloat16, device=gy.device, memory_format=CL3D)
+    halo = split is None and stride == 2 and DGRAD_S2_HALO and ci <= 32 and co in (16, 32, 48)
+    chunks = [(0, n)] if halo else _batch_chunks(n, d * h * w, "conv_dgrad")
+    if len(chunks) > 1:
+        for i, c in chunks:
+            gx[i:i + c] = conv_dgrad(gy[i:i + c], wkt, stride, in_dims, split)
+        return gx
     if stride == 1:
         if split is None:
             split = _split_for(_tiles(n * d * h * w, ci), (27 * co + 63) // 64)
@@ -248,6 +276,13 @@ def conv_wgrad(x, gy, stride):
     co, od, oh, ow = gy.shape[1:]
     if wgrad_ring_supported(ci, co, ow, n * od * oh * ow):
         return conv_wgrad_ring(x, gy, stride)
+    chunks = _batch_chunks(n, od * oh * ow, "conv_wgrad")
+    if len(chunks) > 1:          # the filter gradient is a sum over samples
+        dw = None
+        for i, c in chunks:
+            part = conv_wgrad(x[i:i + c], gy[i:i + c], stride)
+            dw = part if dw is None else dw.add_(part)
+        return dw
     return _wgrad(x, gy, (n, d, h, w, ci, co, od, oh, ow, stride), (TAPS_FWD,) * 3, 27, (co, ci, 3, 3, 3))
 
 

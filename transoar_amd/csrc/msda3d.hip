@@ -405,7 +405,6 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   int* rank = reinterpret_cast<int*>(ws + w.rank);
   int* rec_item = reinterpret_cast<int*>(ws + w.rec_item);
   auto recs = reinterpret_cast<PointRec<A>*>(ws + w.recs);
-  TRANSOAR_CHECK_HIP(zero_async(count, sizeof(int) * w.n_scan, st));
   // cells per (batch, head) slab: needs the level shapes on the host; without them the binning
   // runs as its own kernel (msda3d_cell_count) after the gather
   long cells_per_slab = 0;
@@ -413,26 +412,52 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
     for (int l = 0; l < d.L; ++l)
       cells_per_slab += (host_shapes[3 * l] + 1) * (host_shapes[3 * l + 1] + 1) * (host_shapes[3 * l + 2] + 1);
   const bool fold_count = host_shapes != nullptr && cells_per_slab * d.N * d.M <= w.n_bins;
+  // entries of the count / offset array that are in use: one per cell + the end of the last run (the upper bound
+  // n_bins + 1 = 8 S N M + 1 without host shapes: zeroing and scanning it was 45 MB four times over at the flagship size)
+  const long n_scan = fold_count ? cells_per_slab * d.N * d.M + 1 : w.n_scan;
+  const long n_tiles = (n_scan + kScanTile - 1) / kScanTile;
+  TRANSOAR_CHECK_HIP(zero_async(count, sizeof(int) * n_scan, st));
+  auto scan = [&]() {
+    ProfScope prof(TRANSOAR_PROF_SCAN, st);
+    hipLaunchKernelGGL(msda3d_scan_tiles, dim3(static_cast<unsigned>(n_tiles)), dim3(kScanThreads), 0,
+                       st, count, tile_sums, static_cast<int>(n_scan));
+    hipLaunchKernelGGL(msda3d_scan_tile_sums, dim3(1), dim3(kScanThreads), 0, st, tile_sums,
+                       static_cast<int>(n_tiles));
+    hipLaunchKernelGGL(msda3d_scan_add, dim3(static_cast<unsigned>(n_tiles)), dim3(kScanThreads), 0, st,
+                       count, tile_sums, static_cast<int>(n_scan));
+  };
 
   // 1. grad_loc / grad_attn (+ the binning pass of the point sort when folded)
 #define TRANSOAR_BWDQ(LG)                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
                      at, go, gl, ga, fold_count ? count : nullptr, rank, static_cast<int>(cells_per_slab), \
                      d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
-  bool brick_done = false;
+  bool brick_done = false, recs_done = false;
   if constexpr (sizeof(VT) == 2) {
     bool small = d.L <= kMmaLevels;
     for (int l = 0; small && l < d.L; ++l) small = q_order.D[l] <= 1000 && q_order.H[l] <= 1000 && q_order.W[l] <= 1000;
     if (q_order.enabled && fold_count && small && d.C == 64 && d.P == 4 &&
         !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA))) {
-      ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+      // Matrix-core chain: count the points per cell (locations only), scan, then ONE kernel computes grad_loc /
+      // grad_attn and writes every point's 16-byte record at its sorted position.  The counts go to count[cell + 1]:
+      // after the exclusive scan that slot holds the first position of cell `cell` and serves as its cursor; when the
+      // records are written it has advanced to the first position of cell + 1, i.e. count[] is the offset array the
+      // grad_value walks read (offset[c], offset[c + 1]) without another pass.
       const long n_wave = static_cast<long>(d.N) * (q_order.pad_start[q_order.L] >> 7) * d.M * 4;
       const BrickOrder* order_d = device_const(q_order, st);
       if (order_d == nullptr) return TRANSOAR_ERR_CONST;
-      hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
-                         v, lo, at, go, gl, ga, count, rank, static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes,
-                         n_wave, order_d);
-      brick_done = true;
+      const dim3 qgrid(static_cast<unsigned>(((n_wave + 7) / 8) * 8));
+      {
+        ProfScope prof(TRANSOAR_PROF_CELL_COUNT, st);
+        hipLaunchKernelGGL((msda3d_cell_count_mma<LT>), qgrid, dim3(64), 0, st, lo, count + 1,
+                           static_cast<int>(cells_per_slab), d.S, d.M, d.L, n_wave, order_d);
+      }
+      scan();
+      ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+      hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
+                         v, lo, at, go, gl, ga, count + 1, reinterpret_cast<PointR16*>(ws + w.recs),
+                         static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+      brick_done = recs_done = true;
     }
   }
   if constexpr (sizeof(VT) == 2) {
@@ -460,27 +485,19 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
     hipLaunchKernelGGL((msda3d_cell_count<LT, A>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,
                        rank, d.M, d.L, d.Lq, d.P, w.n_points);
   }
-  {
-  ProfScope prof(TRANSOAR_PROF_SCAN, st);
-  hipLaunchKernelGGL(msda3d_scan_tiles, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0,
-                     st, count, tile_sums, static_cast<int>(w.n_scan));
-  hipLaunchKernelGGL(msda3d_scan_tile_sums, dim3(1), dim3(kScanThreads), 0, st, tile_sums,
-                     static_cast<int>(w.n_tiles));
-  hipLaunchKernelGGL(msda3d_scan_add, dim3(static_cast<unsigned>(w.n_tiles)), dim3(kScanThreads), 0, st,
-                     count, tile_sums, static_cast<int>(w.n_scan));
-  }
+  if (!recs_done) scan();
   BrickOrder r_order = make_order(host_shapes, d, d.S);
   if constexpr (sizeof(A) == 4) {
     // brick-owner schedule: fp32 LDS tile per 4x4x8 brick, 8-weight point records
     if (r_order.enabled && fold_count && d.C == kTileC && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
       auto recs8 = reinterpret_cast<PointW8<float>*>(ws + w.recs);
-      auto recs4 = reinterpret_cast<PointT4*>(ws + w.recs);        // matrix-core walks: 32 bytes with the row index inside
+      auto recs4 = reinterpret_cast<PointR16*>(ws + w.recs);       // matrix-core walks: 16 bytes with the row index inside
       bool mma = false;
       if constexpr (sizeof(VT) == 2) mma = !(flags & TRANSOAR_MSDA3D_NO_MMA);
-      {
+      if (!recs_done) {
         ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
         if (mma)
-          hipLaunchKernelGGL((msda3d_cell_fill_t4<LT>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count, rank, recs4,
+          hipLaunchKernelGGL((msda3d_cell_fill_r16<LT>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count, rank, recs4,
                              d.M, d.L, d.Lq, d.P, w.n_points);
         else
           hipLaunchKernelGGL((msda3d_cell_fill_w8<LT, float>), pgrid, dim3(256), 0, st, lo, at, shapes, lsi, count,

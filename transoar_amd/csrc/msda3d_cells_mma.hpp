@@ -7,7 +7,7 @@
 // is the product  A[32 voxels x K points] . B[K points x 64 channels]  of a weight matrix with two non-zeros
 // per row and point (the point's dw = 0 / 1 corners of that voxel row's (dd, dh)) and the gathered grad_out
 // rows: 16 points per MFMA K-step instead of 16 x (1 load + 8 FMA + scalar bookkeeping) in the lane = channel
-// walk.  The weights (fp32, rebuilt from the 32-byte PointT4 record when it is staged) go to the matrix cores as
+// walk.  The weights (fp32, rebuilt from the 16-byte PointR16 record when it is staged) go to the matrix cores as
 // hi + lo 16-bit halves (two MFMAs, 2^-16 relative), the grad_out rows are 16-bit already: fp32 accumulation of
 // exact products as before.
 //
@@ -29,21 +29,13 @@ constexpr int kCellsWindow = 7;        // cells per window: 8 voxels along w
 constexpr int kCmCellChunk = 1024;     // sorted points per wave of the coarse walk (256: 2.41, 512: 2.35, 1024: 2.31, 2048: 2.44 ms per backward call)
 constexpr int kCmRowPitch = 144;       // bytes per staged grad_out row (128 + 16: spreads the banks, as kMmaVP)
 
-// Record of a sorted point for the matrix-core walks: ONE 32-byte write per point (the 8-weight record + a separate
-// row-index array were two 32-byte write granules: 1.49 GB per call for 0.8 GB of payload).  The 8 corner weights are
-// t[2 dd + dh] * (1 - lw) and t[2 dd + dh] * lw with t = a * fd * fh: two multiplies when a record is staged.
-struct alignas(16) PointT4 {
-  float t[4];
-  float lw;
-  int item;          // row of grad_out, (b * Lq + q) * M + m
-  int pad[2];
-};
-
+// Records from per-point ranks: the fill pass of the problems whose grad_loc / grad_attn kernel is not
+// msda3d_bwd_query_mma (queries that are not the pyramid's voxels), which writes the records itself.
 template <typename LT>
-__global__ __launch_bounds__(256) void msda3d_cell_fill_t4(
+__global__ __launch_bounds__(256) void msda3d_cell_fill_r16(
     const LT* __restrict__ loc, const LT* __restrict__ attn, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const int* __restrict__ offset, const int* __restrict__ rank,
-    PointT4* __restrict__ recs, int M, int L, int Lq, int P, long n_points) {
+    PointR16* __restrict__ recs, int M, int L, int Lq, int P, long n_points) {
   const long j = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (j >= n_points) return;
   const int rk = rank[j];
@@ -51,13 +43,7 @@ __global__ __launch_bounds__(256) void msda3d_cell_fill_t4(
   PointRec<float> rec;
   int item;
   const int bin = point_bin<LT, float>(loc, attn, shapes, lsi, j, M, L, Lq, P, &rec, &item);
-  PointT4 out;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) out.t[g] = rec.a * ((g & 2) ? rec.ld : 1.f - rec.ld) * ((g & 1) ? rec.lh : 1.f - rec.lh);
-  out.lw = rec.lw;
-  out.item = item;
-  out.pad[0] = out.pad[1] = 0;
-  recs[offset[bin] + rk] = out;
+  recs[offset[bin] + rk] = make_point_r16(rec.a, item, rec.ld, rec.lh, rec.lw);
 }
 
 // The K loop shared by the two grad_value kernels: points [t, t_end) of the sorted list, 16 per step, against
@@ -65,7 +51,7 @@ __global__ __launch_bounds__(256) void msda3d_cell_fill_t4(
 // this wave's private staging areas (16 grad_out rows, 16 records).  Indices are clamped to `last`.
 template <typename VT>
 __device__ __forceinline__ void cell_run_mma(
-    const VT* __restrict__ grad_out, const PointT4* __restrict__ recs,
+    const VT* __restrict__ grad_out, const PointR16* __restrict__ recs,
     int t, int t_end, int last, int o0, int o1, unsigned n0, unsigned n1, unsigned char* vrow, float* wrec, int lane,
     f32x16& acc0, f32x16& acc1) {
   constexpr int C = kTileC;
@@ -73,28 +59,28 @@ __device__ __forceinline__ void cell_run_mma(
   const int st_row = lane >> 2, st_q = lane & 3;        // staging: 4 lanes per grad_out row, 2 x 16 bytes each
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  // one K-step = 16 points: their records (512 contiguous bytes: lane = record lane >> 2, 8-byte piece lane & 3) and
-  // grad_out rows, staged one step ahead.  The row index rides in piece 2 of the record; the four lanes of a record
-  // get it through a quad broadcast.
-  uint2 rec_pre;
+  // one K-step = 16 points: their records (256 contiguous bytes; the four lanes that fetch a point's grad_out row
+  // all read its whole 16-byte record -- one request per quad) and grad_out rows, staged one step ahead.
+  u32x4 rec_pre;
   u32x4 row_pre[2];
   auto issue = [&](int s) {
     const int pr = min(s + (lane >> 2), last);
-    rec_pre = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(recs + pr) + (lane & 3) * 8);
-    const long item = __builtin_amdgcn_mov_dpp(static_cast<int>(rec_pre.y), 0xAA, 0xf, 0xf, false);   // quad_perm [2,2,2,2]
+    rec_pre = *reinterpret_cast<const u32x4*>(recs + pr);
+    const long item = static_cast<int>(rec_pre.y);
     const u32x4* src = reinterpret_cast<const u32x4*>(grad_out + item * C);
     row_pre[0] = src[st_q];
     row_pre[1] = src[4 + st_q];
   };
   issue(t);
   for (int s = t; s < t_end; s += 16) {
-    {
-      // expand (t0, t1) / (t2, t3) of pieces 0 / 1 into the 8 weights of the record: [t (1 - lw), t lw] per (dd, dh)
-      const float lw = __int_as_float(__builtin_amdgcn_mov_dpp(static_cast<int>(rec_pre.x), 0xAA, 0xf, 0xf, false));
-      const float ta = __uint_as_float(rec_pre.x), tb = __uint_as_float(rec_pre.y);
+    if ((lane & 2) == 0) {
+      // lanes 0 / 1 of a quad expand the record into the weights of dd = 0 / 1: [t (1 - lw), t lw] per dh
+      float ld, lh, lw;
+      point_r16_fracs(rec_pre.z, rec_pre.w, ld, lh, lw);
+      const float td = __uint_as_float(rec_pre.x) * ((lane & 1) ? ld : 1.f - ld);
+      const float tb = td * lh, ta = td - tb;
       const float ya = ta * lw, yb = tb * lw;
-      if ((lane & 2) == 0)
-        *reinterpret_cast<float4*>(wrec + (lane >> 2) * 8 + (lane & 1) * 4) = float4{ta - ya, ya, tb - yb, yb};
+      *reinterpret_cast<float4*>(wrec + (lane >> 2) * 8 + (lane & 1) * 4) = float4{ta - ya, ya, tb - yb, yb};
     }
     *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + st_q * 16) = row_pre[0];
     *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + 64 + st_q * 16) = row_pre[1];
@@ -128,7 +114,7 @@ __device__ __forceinline__ void cell_run_mma(
 template <typename VT>
 __global__ __launch_bounds__(256, 4) void msda3d_bwd_value_cells_mma(
     const VT* __restrict__ grad_out, const int* __restrict__ offset,
-    const PointT4* __restrict__ recs,
+    const PointR16* __restrict__ recs,
     float* __restrict__ scratch, int cells_per_slab, int n_slabs, int M, const CoarseLevels* __restrict__ cl_p,
     const BrickOrder* __restrict__ order_p) {
   const CoarseLevels& cl = *cl_p;
@@ -220,7 +206,7 @@ __global__ __launch_bounds__(256, 4) void msda3d_bwd_value_cells_mma(
 template <typename VT>
 __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_value_tile_mma(
     const VT* __restrict__ grad_out, const int* __restrict__ offset,
-    const PointT4* __restrict__ recs,
+    const PointR16* __restrict__ recs,
     VT* __restrict__ grad_value, int cells_per_slab, int S, int M, int fine_bricks, long n_wg, const BrickOrder* __restrict__ order_p) {
   const BrickOrder& order = *order_p;
   constexpr int C = kTileC;

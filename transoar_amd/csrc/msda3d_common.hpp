@@ -255,4 +255,30 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long nblk) {
   return swz < nblk ? swz : -1;
 }
 
+// Record of a sorted point for the matrix-core walks: 16 bytes, ONE write per point.  Round 2's record was 32 bytes
+// (four products a * f_d * f_h, l_w, the row index, 8 bytes of padding): 0.72 GB written and read back per call at the
+// flagship size.  The three fractions l_d, l_h, l_w in [0, 1) are stored as 21-bit fixed point (2^-22 absolute error:
+// finer than the fp32 rounding of the pixel coordinate they are cut from once a level has more than 32 voxels on an
+// axis), the attention weight and the grad_out row stay 32 bits.  The 8 corner weights are rebuilt when a record is
+// staged: t[2 dd + dh] = a * f_d * f_h, then t * (1 - l_w) and t * l_w.
+struct alignas(16) PointR16 {
+  float a;
+  int item;          // row of grad_out, (b * Lq + q) * M + m
+  unsigned lo, hi;   // l_d | l_h << 21 | l_w << 42
+};
+constexpr float kFracScale = 2097152.f;          // 2^21
+__device__ __forceinline__ unsigned frac21(float f) {
+  return min(static_cast<unsigned>(f * kFracScale + 0.5f), 0x1fffffu);
+}
+__device__ __forceinline__ PointR16 make_point_r16(float a, int item, float ld, float lh, float lw) {
+  const unsigned qd = frac21(ld), qh = frac21(lh), qw = frac21(lw);
+  return PointR16{a, item, qd | (qh << 21), (qh >> 11) | (qw << 10)};
+}
+__device__ __forceinline__ void point_r16_fracs(unsigned lo, unsigned hi, float& ld, float& lh, float& lw) {
+  constexpr float inv = 1.f / kFracScale;
+  ld = static_cast<float>(lo & 0x1fffffu) * inv;
+  lh = static_cast<float>((lo >> 21) | ((hi & 0x3ffu) << 11)) * inv;
+  lw = static_cast<float>(hi >> 10) * inv;
+}
+
 }  // namespace transoar

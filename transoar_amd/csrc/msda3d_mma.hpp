@@ -430,21 +430,75 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
 }
 
 
+// The two sampling points of lane (query j, half kg) on level l and the wave's corner-voxel bounding box: shared by
+// msda3d_bwd_query_mma and the counting pre-pass of its point sort (msda3d_cell_count_mma), which must agree on the
+// cell of every point bit for bit.  attn may be NULL (weights 0).  Returns false when the wave has no valid point.
+template <typename LT>
+__device__ __forceinline__ bool mma_level_points(const BrickOrder& order, int l, bool live, long item, int LP, int kg,
+                                                 const LT* __restrict__ loc, const LT* __restrict__ attn,
+                                                 MmaPoint (&pt)[2], MmaBox& box) {
+  constexpr int P = 4;
+  box = MmaBox{0, 0, 0, 0, 0, 0};
+  const int D = order.D[l], H = order.H[l], W = order.W[l];
+  int lo_d = 32767, lo_h = 32767, lo_w = 32767, hi_d = -1, hi_h = -1, hi_w = -1;
+  float lx[2] = {0.f, 0.f}, ly[2] = {0.f, 0.f}, lz[2] = {0.f, 0.f}, la[2] = {0.f, 0.f};
+  if (live) {
+    const long jx = item * LP + l * P + 2 * kg;
+    if constexpr (sizeof(LT) == 4) {
+      const float2 q0 = *reinterpret_cast<const float2*>(loc + 3 * jx), q1 = *reinterpret_cast<const float2*>(loc + 3 * jx + 2),
+                   q2 = *reinterpret_cast<const float2*>(loc + 3 * jx + 4), qa = attn ? *reinterpret_cast<const float2*>(attn + jx) : float2{0.f, 0.f};
+      lx[0] = q0.x; ly[0] = q0.y; lz[0] = q1.x; lx[1] = q1.y; ly[1] = q2.x; lz[1] = q2.y;
+      la[0] = qa.x; la[1] = qa.y;
+    } else {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        lx[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi)));
+        ly[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 1));
+        lz[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 2));
+        la[pi] = attn ? static_cast<float>(Elem<LT>::ld(attn + jx + pi)) : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    MmaPoint g{0x3fffffff, 0.f, 0.f, 0.f, 0.f};
+    const float w_im = pixel_coord(lx[pi], W), h_im = pixel_coord(ly[pi], H), d_im = pixel_coord(lz[pi], D);
+    if (live && d_im > -1.f && h_im > -1.f && w_im > -1.f && d_im < D && h_im < H && w_im < W) {
+      const float fd = floorf(d_im), fh = floorf(h_im), fw = floorf(w_im);
+      const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
+      g.dhw = (d0 + 1) | ((h0 + 1) << 10) | ((w0 + 1) << 20);
+      g.ld = d_im - fd; g.lh = h_im - fh; g.lw = w_im - fw; g.a = la[pi];
+      lo_d = min(lo_d, max(d0, 0)); hi_d = max(hi_d, min(d0 + 1, D - 1));
+      lo_h = min(lo_h, max(h0, 0)); hi_h = max(hi_h, min(h0 + 1, H - 1));
+      lo_w = min(lo_w, max(w0, 0)); hi_w = max(hi_w, min(w0 + 1, W - 1));
+    }
+    pt[pi] = g;
+  }
+  const int r0 = wave_min_pk16(pack16(lo_d, lo_h)), r1 = wave_min_pk16(pack16(lo_w, -hi_d)), r2 = wave_min_pk16(pack16(-hi_h, -hi_w));
+  hi_d = -(r1 >> 16);
+  if (hi_d < 0) return false;
+  lo_d = static_cast<short>(r0); lo_h = r0 >> 16; lo_w = static_cast<short>(r1);
+  hi_h = -static_cast<int>(static_cast<short>(r2)); hi_w = -(r2 >> 16);
+  box = MmaBox{lo_d, lo_h, lo_w, hi_d - lo_d + 1, hi_h - lo_h + 1, hi_w - lo_w + 1};
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // grad_sampling_loc / grad_attn_weight on the matrix cores, same wave = 32 queries x 1 head structure.
 // Per (point, corner) the backward needs  dot = <grad_out[q, :], value[row, :]>  -- for the 32 queries of a wave
 // against the rows of their box that is the product  G[r, q] = V[r, c] . GO^T[c, q]  (64 channels = 4 MFMA
 // K-steps, both operands read with their channel axis contiguous: no transposes, products of 16-bit values
 // exact in fp32).  G goes through an LDS block [row][query]; every lane picks its 16 corner dots out of it
-// and finishes its two points at the end of the level.  Also does the binning pass of the grad_value point
-// sort (rank of every point inside its cell): an LDS histogram over the wave's cell box, then one returning
-// global atomic per touched cell.
+// and finishes its two points at the end of the level.  Also does the second pass of the grad_value point
+// sort: it writes every point's 16-byte record (PointR16) at its sorted position -- an LDS histogram over the
+// wave's cell box, then one returning global atomic per touched cell on the cells' cursors (round 3 had a third
+// kernel re-read loc / attn / the ranks and write the records: 1.65 GB and 0.42 ms per call).
 // ---------------------------------------------------------------------------
 template <typename VT, typename LT>
 __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
     const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
-    int* __restrict__ bin_count, int* __restrict__ bin_rank, int cells_per_slab, int S, int M, int L,
+    int* __restrict__ cursor, PointR16* __restrict__ recs, int cells_per_slab, int S, int M, int L,
     unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
   const BrickOrder& order = *order_p;
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
@@ -487,47 +541,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     constexpr int l = decltype(lc)::value;
     box[l] = MmaBox{0, 0, 0, 0, 0, 0};
     if (l >= L) return;
-    const int D = order.D[l], H = order.H[l], W = order.W[l];
-    int lo_d = 32767, lo_h = 32767, lo_w = 32767, hi_d = -1, hi_h = -1, hi_w = -1;
-    float lx[2] = {0.f, 0.f}, ly[2] = {0.f, 0.f}, lz[2] = {0.f, 0.f}, la[2] = {0.f, 0.f};
-    if (live) {
-      const long jx = item * LP + l * P + 2 * kg;
-      if constexpr (sizeof(LT) == 4) {
-        const float2 q0 = *reinterpret_cast<const float2*>(loc + 3 * jx), q1 = *reinterpret_cast<const float2*>(loc + 3 * jx + 2),
-                     q2 = *reinterpret_cast<const float2*>(loc + 3 * jx + 4), qa = *reinterpret_cast<const float2*>(attn + jx);
-        lx[0] = q0.x; ly[0] = q0.y; lz[0] = q1.x; lx[1] = q1.y; ly[1] = q2.x; lz[1] = q2.y;
-        la[0] = qa.x; la[1] = qa.y;
-      } else {
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-          lx[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi)));
-          ly[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 1));
-          lz[pi] = static_cast<float>(Elem<LT>::ld(loc + 3 * (jx + pi) + 2));
-          la[pi] = static_cast<float>(Elem<LT>::ld(attn + jx + pi));
-        }
-      }
-    }
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      MmaPoint g{0x3fffffff, 0.f, 0.f, 0.f, 0.f};
-      const float w_im = pixel_coord(lx[pi], W), h_im = pixel_coord(ly[pi], H), d_im = pixel_coord(lz[pi], D);
-      if (live && d_im > -1.f && h_im > -1.f && w_im > -1.f && d_im < D && h_im < H && w_im < W) {
-        const float fd = floorf(d_im), fh = floorf(h_im), fw = floorf(w_im);
-        const int d0 = static_cast<int>(fd), h0 = static_cast<int>(fh), w0 = static_cast<int>(fw);
-        g.dhw = (d0 + 1) | ((h0 + 1) << 10) | ((w0 + 1) << 20);
-        g.ld = d_im - fd; g.lh = h_im - fh; g.lw = w_im - fw; g.a = la[pi];
-        lo_d = min(lo_d, max(d0, 0)); hi_d = max(hi_d, min(d0 + 1, D - 1));
-        lo_h = min(lo_h, max(h0, 0)); hi_h = max(hi_h, min(h0 + 1, H - 1));
-        lo_w = min(lo_w, max(w0, 0)); hi_w = max(hi_w, min(w0 + 1, W - 1));
-      }
-      pt[l][pi] = g;
-    }
-    const int r0 = wave_min_pk16(pack16(lo_d, lo_h)), r1 = wave_min_pk16(pack16(lo_w, -hi_d)), r2 = wave_min_pk16(pack16(-hi_h, -hi_w));
-    hi_d = -(r1 >> 16);
-    if (hi_d < 0) return;
-    lo_d = static_cast<short>(r0); lo_h = r0 >> 16; lo_w = static_cast<short>(r1);
-    hi_h = -static_cast<int>(static_cast<short>(r2)); hi_w = -(r2 >> 16);
-    box[l] = MmaBox{lo_d, lo_h, lo_w, hi_d - lo_d + 1, hi_h - lo_h + 1, hi_w - lo_w + 1};
+    mma_level_points<LT>(order, l, live, item, LP, kg, loc, attn, pt[l], box[l]);
   });
 
   for (int i = lane; i < WR * 32 / 4; i += 64) reinterpret_cast<float4*>(gbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
@@ -556,17 +570,16 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
   u32x4 pre[8];
   bool have_pre = false;
   int cell_start = 0;
-  // The results of a lane (per level: 2 points x (3 + 1) gradients, 2 ranks) stay in registers until the end of the
+  // The results of a lane (per level: 2 points x (3 + 1) gradients) stay in registers until the end of the
   // wave: written level by level, the four 8..24-byte pieces of a query's 64 / 192-byte rows arrive microseconds
   // apart with 20 MB of such rows in flight on the chip, and L2 evicted the half-written lines (WRITE_SIZE 2.3 x
   // the payload).
   float res_a[kMmaLevels][2], res_l[kMmaLevels][2][3];
-  int res_rank[kMmaLevels][2];
   static_for<0, kMmaLevels>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
-      res_a[l][pi] = 0.f; res_rank[l][pi] = -1;
+      res_a[l][pi] = 0.f;
       res_l[l][pi][0] = 0.f; res_l[l][pi][1] = 0.f; res_l[l][pi][2] = 0.f;
     }
   });
@@ -581,9 +594,12 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const MmaBox bx = box[l];
     const int THW = bx.TH * bx.TW, R = bx.TD * THW;
 
-    // ---- binning pass of the point sort
-    if (bin_count != nullptr) {
-      int* slab_count = bin_count + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
+    // ---- second pass of the point sort: the sorted position of every point of the wave and its 16-byte record.
+    // cursor[cell] holds the next free position of the cell's run (the counting pre-pass msda3d_cell_count_mma and the
+    // scan put the run's first position there): a wave reserves the places of all its points of a cell with ONE
+    // returning atomic (LDS histogram over the wave's cell box first) and writes the records there and then.
+    if (cursor != nullptr) {
+      int* slab_cursor = cursor + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
       int* hist = reinterpret_cast<int*>(gbuf);
       const int CH = bx.TH + 1, CW = bx.TW + 1;
       const int ncells = (bx.TD + 1) * CH * CW;
@@ -601,7 +617,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
           lcell[pi] = ((c1d - bx.bd) * CH + (c1h - bx.bh)) * CW + (c1w - bx.bw);
           rank[pi] = atomicAdd(&hist[lcell[pi]], 1);
         } else {
-          rank[pi] = atomicAdd(slab_count + (c1d * (H + 1) + c1h) * (W + 1) + c1w, 1);
+          rank[pi] = atomicAdd(slab_cursor + (c1d * (H + 1) + c1h) * (W + 1) + c1w, 1);
         }
       }
       if (use_hist) {
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
             if (n > 0) {
               const int cd = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_chw), cr = c - cd * (CH * CW);
               const int ch = static_cast<int>((static_cast<float>(cr) + 0.5f) * inv_cw), cw = cr - ch * CW;
-              base[k] = atomicAdd(slab_count + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
+              base[k] = atomicAdd(slab_cursor + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
             }
           }
 #pragma unroll
@@ -630,8 +646,11 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
           if (rank[pi] >= 0) rank[pi] += hist[lcell[pi]];
         // the histogram lived in the G block: its spare row was not touched, the rest is rewritten before use
       }
-      res_rank[l][0] = rank[0];
-      res_rank[l][1] = rank[1];
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const MmaPoint g = pt[l][pi];
+        if (rank[pi] >= 0) recs[rank[pi]] = make_point_r16(g.a, static_cast<int>(item), g.ld, g.lh, g.lw);
+      }
     }
 
     // ---- this lane's 16 corner slots: word offset in a G block that would hold the whole box
@@ -781,7 +800,6 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
       constexpr int l = decltype(lc)::value;
       if (l >= L) return;
       const long jx = item * LP + l * P + 2 * kg;          // even: 8-byte aligned pairs
-      if (bin_count != nullptr) *reinterpret_cast<int2*>(bin_rank + jx) = int2{res_rank[l][0], res_rank[l][1]};
       if constexpr (sizeof(LT) == 4) {
         *reinterpret_cast<float2*>(grad_attn + jx) = float2{res_a[l][0], res_a[l][1]};
         float2* gl = reinterpret_cast<float2*>(grad_loc + 3 * jx);
@@ -798,6 +816,77 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
       }
     });
   }
+}
+
+// ---------------------------------------------------------------------------
+// Counting pre-pass of the point sort: the number of valid sampling points per cell, with the unit decomposition and
+// the geometry (mma_level_points) of msda3d_bwd_query_mma, so that both passes see the same cell for every point.
+// Reads the locations only (270 MB at the flagship size); an LDS histogram over the wave's cell box, then ONE
+// non-returning global atomic per touched cell.  count = the slot of cell 0 (the caller shifts the array by one
+// entry, so that the exclusive scan leaves every cell's first position in its cursor slot).
+// ---------------------------------------------------------------------------
+template <typename LT>
+__global__ __launch_bounds__(64) void msda3d_cell_count_mma(
+    const LT* __restrict__ loc, int* __restrict__ count, int cells_per_slab, int S, int M, int L, long n_units,
+    const BrickOrder* __restrict__ order_p) {
+  const BrickOrder& order = *order_p;
+  constexpr int P = 4, KB = kMmaKB;
+  __shared__ int hist[KB * 32];
+
+  const long u = xcd_contiguous_block(blockIdx.x, n_units);
+  if (u < 0) return;
+  const int lane = threadIdx.x;
+  const int j = lane & 31, kg = lane >> 5;
+  const int sb = static_cast<int>(u & 3);
+  const long t1 = u >> 2;
+  const int m = static_cast<int>(t1 % M);
+  const long t2 = t1 / M;
+  const int bricks = order.pad_start[order.L] >> 7;
+  const int brick = bricks - 1 - static_cast<int>(t2 % bricks);
+  const long b = t2 / bricks;
+  const int slot = (2 * (sb >> 1) + (j >> 4)) * 32 + ((j >> 2) & 3) * 8 + 4 * (sb & 1) + (j & 3);
+  const int s = brick_slot_to_row(order, brick * kBrickSlots + slot);
+  const bool live = s >= 0;
+  const long item = live ? (b * S + s) * M + m : 0;
+  const int LP = L * P;
+
+  int cell_start = 0;
+  static_for<0, kMmaLevels>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if (l >= L) return;
+    const int D = order.D[l], H = order.H[l], W = order.W[l];
+    const int my_cell_start = cell_start;
+    cell_start += (D + 1) * (H + 1) * (W + 1);
+    MmaPoint pt[2];
+    MmaBox bx;
+    if (!mma_level_points<LT>(order, l, live, item, LP, kg, loc, static_cast<const LT*>(nullptr), pt, bx)) return;
+    int* slab_count = count + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
+    const int CH = bx.TH + 1, CW = bx.TW + 1;
+    const int ncells = (bx.TD + 1) * CH * CW;
+    const bool use_hist = ncells <= KB * 32;
+    if (use_hist) {
+      for (int c = lane; c < ncells; c += 64) hist[c] = 0;
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int dhw = pt[pi].dhw;
+      if (dhw == 0x3fffffff) continue;
+      const int c1d = dhw & 1023, c1h = (dhw >> 10) & 1023, c1w = (dhw >> 20) & 1023;      // d0+1, h0+1, w0+1
+      if (use_hist) atomicAdd(&hist[((c1d - bx.bd) * CH + (c1h - bx.bh)) * CW + (c1w - bx.bw)], 1);
+      else atomicAdd(slab_count + (c1d * (H + 1) + c1h) * (W + 1) + c1w, 1);
+    }
+    if (use_hist) {
+      const float inv_chw = __builtin_amdgcn_rcpf(static_cast<float>(CH * CW)), inv_cw = __builtin_amdgcn_rcpf(static_cast<float>(CW));
+      for (int c = lane; c < ncells; c += 64) {
+        const int n = hist[c];
+        if (n > 0) {
+          const int cd = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_chw), cr = c - cd * (CH * CW);
+          const int ch = static_cast<int>((static_cast<float>(cr) + 0.5f) * inv_cw), cw = cr - ch * CW;
+          atomicAdd(slab_count + ((bx.bd + cd) * (H + 1) + (bx.bh + ch)) * (W + 1) + (bx.bw + cw), n);
+        }
+      }
+    }
+  });
 }
 
 }  // namespace transoar

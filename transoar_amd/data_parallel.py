@@ -139,14 +139,20 @@ class GradientAllReducer:
         if not self.overlap:         # captured-graph step: the exchange runs after the replay
             for b in self.buckets:
                 b.handle = None
+        self.exchange()
+        self._end_first_step()
+
+    def exchange(self):
+        """Launch every bucket that is not in flight yet, wait for all of them and widen compressed buckets back
+        (the tail of the eager step, and the whole exchange of the captured step, which has no hooks running)."""
         for b in self.buckets:
-            if b.handle is None:     # first step only: a parameter without gradient held it back
+            if b.handle is None:     # eager: first step only (a parameter without gradient held the bucket back)
                 b.handle = self._launch(b)
         for b in self.buckets:
             b.handle.wait()
             if b.wire is not None:
                 b.flat.copy_(b.wire)
-        self._end_first_step()
+            b.handle = None
 
     def _end_first_step(self):
         if not (self._first_step and self.flat):

@@ -210,8 +210,10 @@ class TrainStep:
         return self
 
     def _snapshot(self):
-        """Copies of every parameter and of the optimizer's state tensors (None where the state does not exist yet)."""
-        params = [p.detach().clone() for p in self.model.parameters()]
+        """Copies of every parameter and module buffer, of the optimizer's state tensors (None where the state does not
+        exist yet) and of the device's RNG state (the warm-up steps and the verification replay draw dropout seeds)."""
+        params = [p.detach().clone() for p in list(self.model.parameters()) + list(self.model.buffers())]
+        self._snap_rng = torch.cuda.get_rng_state(next(self.model.parameters()).device)
         state = []
         for group in self.optimizer.param_groups:
             for p in group["params"]:
@@ -223,8 +225,9 @@ class TrainStep:
         """In place (the captured graph holds the addresses): parameters back to the snapshot, optimizer state back to
         the snapshot or -- where it was created after the snapshot -- to its initial zeros."""
         params, state = snap
+        torch.cuda.set_rng_state(self._snap_rng, next(self.model.parameters()).device)
         with torch.no_grad():
-            for p, c in zip(self.model.parameters(), params):
+            for p, c in zip(list(self.model.parameters()) + list(self.model.buffers()), params):
                 p.copy_(c)
             i = 0
             for group in self.optimizer.param_groups:
@@ -278,11 +281,7 @@ class TrainStep:
                 self.drop_graph()
                 raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
         if self.reducer.active:
-            for b in self.reducer.buckets:
-                b.handle = torch.distributed.all_reduce(b.flat, op=torch.distributed.ReduceOp.SUM,
-                                                        group=self.reducer.group, async_op=True)
-            for b in self.reducer.buckets:
-                b.handle.wait()
+            self.reducer.exchange()          # the same path as the eager step's finish(): wire compression included
         if not self.capture_optimizer:
             self._clip()
             self.optimizer.step()
