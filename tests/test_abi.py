@@ -184,3 +184,28 @@ def test_convgemm_and_fused_gather_argument_errors():
     assert g(p16, p16, p16, 8, p16, 1, 8, 6, 64, 1, 4, 0, ctypes.addressof(shapes), None) == -3      # fp32 value: 16-bit storage only
     assert g(p16, p16, p16, 8, p16, 1, 8, 6, 32, 1, 4, 2, ctypes.addressof(shapes), None) == -2      # 32 channels per head: not this kernel's form
     assert g(p16, p16, p16, 5, p16, 1, 8, 6, 64, 1, 4, 2, ctypes.addressof(shapes), None) == -2      # reference rows: S or N * S
+
+
+def test_roi_attention_argument_errors():
+    """include/transoar_attn.h (fused masked cross-attention): host-side validation."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_attn.so"))
+    buf = (ctypes.c_char * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    p, i, lg, z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+    lib.transoar_roi_attn_workspace_bytes.restype = z
+    lib.transoar_roi_attn_workspace_bytes.argtypes = [i, i, i]
+    assert lib.transoar_roi_attn_workspace_bytes(40, 216, 1) >= 40 * 216 * 4
+    assert lib.transoar_roi_attn_workspace_bytes(40, 216, 3) >= 40 * 216 * (4 + 3 * 384 * 4 + 2 * 3 * 4)
+    assert lib.transoar_roi_attn_workspace_bytes(0, 216, 1) == 0
+    f = lib.transoar_roi_attn_forward
+    f.argtypes = [p] * 8 + [z, i, i, i, lg, i, i, p]
+    assert f(None, p16, p16, p16, p16, p16, p16, p16, 0, 1, 1, 8, 32, 384, 1, None) == -1
+    assert f(p16, p16, p16, p16, p16, p16, p16, p16, 1 << 20, 1, 1, 8, 32, 256, 1, None) == -2       # C != 384
+    assert f(p16, p16, p16, p16, p16, p16, p16, p16, 1 << 20, 3, 2, 8, 32, 384, 1, None) == -2       # G not a multiple of O
+    assert f(p16, p16, p16, p16, p16, p16, p16, p16, 1 << 20, 1, 1, 600, 32, 384, 1, None) == -2     # more than 512 rows per group
+    assert f(p16, p16, p16, p16, p16, p16, p16, p16, 0, 1, 1, 8, 32, 384, 2, None) == -3             # workspace too small
+    b = lib.transoar_roi_attn_backward
+    b.argtypes = [p] * 11 + [z, i, i, i, lg, i, i, p]
+    assert b(p16, p16, p16, p16, p16, p16, p16, p16, None, p16, p16, 1 << 20, 1, 1, 8, 32, 384, 1, None) == -1
+    assert b(p16, p16, p16, p16, p16, p16, p16, p16, p16, p16, p16, 16, 1, 1, 8, 32, 384, 1, None) == -3
+    assert lib.transoar_attn_abi_version() == 1

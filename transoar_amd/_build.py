@@ -28,6 +28,7 @@ LIBS = {
     "libtransoar_tokens.so": ["tokens.hip"],
     "libtransoar_gemm.so": ["gemm.hip"],
     "libtransoar_convgemm.so": ["conv_gemm.hip"],
+    "libtransoar_attn.so": ["attn.hip"],
 }
 
 

@@ -1,0 +1,711 @@
+// Fused masked cross-attention of the Focused Decoder over per-organ gathered tokens (gfx950).
+//
+// Reference semantics: FocusedAttn.forward, transoar/models/necks/focused_decoder.py:228-262 (scores over all keys,
+// -inf outside the organ's attn_area :138-159,243-247, softmax, weighted sum of the values).  The host side
+// (transoar_amd/focused_decoder.py) has already gathered each organ's RoI tokens and folded the K / V projections into
+// the queries, so what is left per group g = (batch, organ) is ONE plain attention
+//
+//     ctx[g] = softmax( mask( qf[g] (R x C)  .  k[g]^T (C x L) ) )  .  v[g] (L x C)          R = 216, C = 384, L <= 5520
+//
+// whose backward is  dqf = dS k,  dtok = dS^T qf + P^T dctx  with  dS = P o (dctx v^T - rowsum(dctx o ctx)).
+// Round 3 ran it as torch bmm / masked_fill_ / softmax / baddbmm_ (hipBLASLt + aten, a bf16 score tensor in HBM);
+// here QK^T -> mask -> softmax -> PV is one kernel (flash style: online softmax, no score tensor), and the backward
+// recomputes P from the saved log-sum-exp in two kernels: a query-stationary one for dqf and a key-stationary one for
+// dtok (each output is owned by one workgroup: no atomics).
+//
+// Common structure of the three kernels, shaped by C = 384 (a 32-row operand tile is 24 KB, an accumulator tile
+// 32 x 384 fp32 is 192 registers):
+//   * 256 threads = 4 waves, ONE wave per SIMD with the whole 512-register file: the stationary operands of a wave's
+//     32 rows (24 MFMA B fragments each: 96 registers) and its 32 x 384 accumulator live in registers; only the streamed
+//     operand tiles go through LDS;
+//   * streamed tiles (32 rows x 768 B) arrive by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction,
+//     no staging registers) into a 2-deep ring, one barrier per tile;
+//   * one LDS image serves both MFMA fragment reads: 16-byte piece p of row n sits at piece p ^ (4 (n & 3) | (n >> 2) & 3)
+//     -- the 16 rows of a ds_read_b128 lane group land in 16 different 4-bank slots, and the four 64-byte windows of a
+//     transposing ds_read_b64_tr_b16 (rows n .. n + 3) tile the 64 banks.  The image is lane-linear for the DMA; the
+//     permutation is applied to the per-lane SOURCE address;
+//   * scores are computed transposed (S^T = K Q^T) so that a lane holds 16 keys of ONE query row: row maxima / sums
+//     are in-lane plus one exchange between the wave halves, and P^T goes back into the matrix cores as a B operand
+//     after v_cvt_pk_bf16_f32 + v_permlane32_swap (no LDS round trip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_attn.h"
+
+namespace transoar {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int kC = 384;                      // channels of a token (the folded attention's head dimension)
+constexpr int kRowBytes = kC * 2;            // 768
+constexpr int kKS = kC / 16;                 // 24 MFMA K steps over the channels
+constexpr int kCT = kC / 32;                 // 12 channel tiles of an accumulator
+constexpr int kTile = 32 * kRowBytes;        // 24 576 bytes: 32 rows
+constexpr int kMaxRowTiles = 16;             // rows of a group <= 512 (key-stationary kernel: row statistics of the whole group in LDS)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int tile_swz(int n) { return ((n & 3) << 2) | ((n >> 2) & 3); }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// (bf16(b) << 16) | bf16(a), round to nearest even
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// v_exp_f32 as it is (exp2f() adds a denormal-range rescue: three more instructions per value); arguments here are <= ~0
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
+
+// One 32-row tile of a dense (rows, C) bf16 matrix, global -> LDS by DMA (buffer_load_dwordx4 ... lds: 16 bytes per
+// lane, the LDS side is lane-linear).  rs: descriptor of the whole matrix, tile_byte: byte offset of the tile's row 0
+// (wave-uniform, < 2^32).  Rows past the end of the matrix read as zeros (hardware range check); rows of the next
+// group are finite data -- whoever consumes such rows masks their contribution.
+// Wave w issues pieces [6 w, 6 w + 6) of 1 KiB; lane i of piece j fills LDS bytes (6 w + j) * 1024 + 16 i.
+//
+// The loads are inline assembly on purpose: issued through __builtin_amdgcn_raw_ptr_buffer_load_lds, hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first transposing LDS read that follows (it cannot tell the DMA's LDS
+// destination from the read's source), i.e. the next tile's DMA would only overlap half of a tile's MFMA work.
+// hipcc neither counts these loads nor waits for them: every tile loop ends with dma_wait() before its barrier, and
+// nothing else in the loops is a vector memory operation.  M0 (the LDS destination base) is saved and restored in
+// the statement that uses it; the leading s_nop covers the SGPR-write -> VMEM-read hazard of freshly computed operands.
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, unsigned tile_byte, unsigned char* lds_tile, int wave, int lane) {
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_tile));
+  const unsigned soff = __builtin_amdgcn_readfirstlane(tile_byte);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int piece = 6 * wave + j;
+    const int o = piece * 1024 + 16 * lane;
+    const int n = ((o >> 8) * 171) >> 9;                 // o / 768 for o < 24 576
+    const int q = (o - n * kRowBytes) >> 4;               // physical 16-byte piece inside the row
+    const int p = q ^ tile_swz(n);                        // the logical piece that lives there
+    const int voff = n * kRowBytes + p * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + piece * 1024);
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+        : "memory");
+  }
+}
+// every DMA of this wave has landed (then a barrier, then the reads)
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t matrix_rsrc(const unsigned short* base, long rows) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0, static_cast<int>(rows * kRowBytes), 0x00020000);
+}
+
+// Per-lane LDS byte offsets of the two fragment reads inside a tile, reduced to 16 registers: everything else about
+// a read (which tile of the ring stage, K step, channel tile, row half) is an immediate offset of the ds_read.
+// (Written as one address expression per read, hipcc hoists ~70 loop-invariant addresses out of the tile loop and
+// spills a hundred registers around it.)
+//   rows: fragment [32 rows (lane & 31)][16 channels of K step ks]: lane = (row n, half kh) reads the 8 channels
+//         16 ks + 8 kh .. + 7 of row n = logical piece 2 ks + kh = 16 (ks >> 3) + (2 (ks & 7) + kh): the swizzle only
+//         touches the low four bits -> offset rows[ks & 7] + 256 (ks >> 3)
+//   cols: fragment of the TRANSPOSED tile [32 channels of tile ct (lane & 31)][16 rows 16 j + 8 kh .. + 7]: two
+//         transposing reads of 4 rows x 64 bytes per 32 lanes (the addressing msda3d_pcm.hpp uses for V): lane (kh, g, r, c)
+//         supplies row n = 16 j + 8 kh + r (+ 4), channels 32 ct + 16 g + 4 c .. + 3, i.e. piece 4 ct + 2 g + (c >> 1),
+//         byte 8 (c & 1) of it.  swz(n) = 4 r | 2 kh (+ 1 for the second read): with ct = 4 a + b the swizzled piece is
+//         16 a + 4 (b ^ r) + ((2 g + (c >> 1)) ^ (2 kh (+ 1))) -> offset cols[b][i] + 256 a + 12288 j
+struct FragBase {
+  int rows[8];
+  int cols[4][2];
+};
+__device__ __forceinline__ FragBase frag_base(int lane) {
+  FragBase fb;
+  const int n = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) fb.rows[e] = n * kRowBytes + (((2 * e + kh) ^ tile_swz(n)) << 4);
+  const int r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
+  const int lp = 2 * g + (c >> 1);
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      fb.cols[b][i] = (8 * kh + r + 4 * i) * kRowBytes + 64 * (b ^ r) + 16 * (lp ^ (2 * kh + i)) + 8 * (c & 1);
+  return fb;
+}
+// move the bases by `delta` bytes (to the other ring stage), in place and opaque to the optimiser: a second set of
+// bases costs 16 registers the backward kernels do not have, and visible arithmetic is folded back into ~70 hoisted
+// addresses
+__device__ __forceinline__ void frag_shift(FragBase& fb, int delta) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    fb.rows[e] += delta;
+    asm volatile("" : "+v"(fb.rows[e]));
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fb.cols[b][i] += delta;
+      asm volatile("" : "+v"(fb.cols[b][i]));
+    }
+}
+template <int TILE_OFF>
+__device__ __forceinline__ s16x8 frag_rows(const unsigned char* lds, const FragBase& fb, int ks) {
+  return *reinterpret_cast<const s16x8*>(lds + fb.rows[ks & 7] + (TILE_OFF + 256 * (ks >> 3)));
+}
+template <int TILE_OFF>
+__device__ __forceinline__ s16x8 frag_cols(const unsigned char* lds, const FragBase& fb, int j, int ct) {
+  const int imm = TILE_OFF + 256 * (ct >> 2) + 16 * kRowBytes * j;
+  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + fb.cols[ct & 3][0] + imm));
+  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + fb.cols[ct & 3][1] + imm));
+  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 16 fp32 values of a 32x32 MFMA result column (entries (r & 3) + 8 (r >> 2) + 4 kh) -> the two B operand fragments
+// [k = entry 16 j + 8 kh .. + 7][n = lane & 31] in bf16: v_cvt_pk_bf16_f32 + v_permlane32_swap between the wave halves.
+__device__ __forceinline__ void packed_column_to_b_frags(const unsigned (&pk)[8], s16x8 (&frag)[2]) {      // pk[i] = entries 2 i, 2 i + 1
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * j], pk[4 * j + 2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * j + 1], pk[4 * j + 3], false, false);
+    frag[j] = __builtin_bit_cast(s16x8, u32x4{s0[0], s1[0], s0[1], s1[1]});
+  }
+}
+__device__ __forceinline__ void column_to_b_frags(const float (&v)[16], s16x8 (&frag)[2]) {
+  unsigned pk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pk[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
+  packed_column_to_b_frags(pk, frag);
+}
+
+// the stationary B fragments of one wave: 24 x 16 bytes of row `row` (clamped by the caller) of a (rows, C) matrix
+__device__ __forceinline__ void load_row_frags(const unsigned short* __restrict__ row_ptr, int kh, s16x8 (&f)[kKS]) {
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) f[ks] = *reinterpret_cast<const s16x8*>(row_ptr + 16 * ks + 8 * kh);
+}
+// "the value is needed HERE": makes hipcc wait for the load that produces it at this point.  Every ordinary load of
+// a kernel is pinned like this before its tile loop: a counted wait that hipcc would otherwise place inside the loop
+// (vmcnt(N) for a load issued before it) also waits for the loop's DMA loads, which hipcc does not know of.
+template <typename T> __device__ __forceinline__ void need(T& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void need_frags(s16x8 (&f)[kKS]) {
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) need(f[ks]);
+}
+
+// key range of this workgroup: tiles [t0, t1) of the organ's n_tiles, split into n_split equal chunks
+__device__ __forceinline__ void split_range(int tiles, int n_split, int split, int& t0, int& t1) {
+  const int chunk = (tiles + n_split - 1) / n_split;
+  t0 = min(split * chunk, tiles);
+  t1 = min(t0 + chunk, tiles);
+}
+
+#define TRANSOAR_ATTN_KERNEL __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+
+// ---------------------------------------------------------------------------
+// forward: grid (n_split, row blocks of 128, G)
+//   n_split == 1: ctx (bf16) and lse written directly; else unnormalised partials (pacc fp32, pm, pl) for attn_fwd_combine
+// ---------------------------------------------------------------------------
+TRANSOAR_ATTN_KERNEL void roi_attn_fwd(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k, const unsigned short* __restrict__ v,
+    const unsigned* __restrict__ keybits, const int* __restrict__ n_tiles, unsigned short* __restrict__ ctx,
+    float* __restrict__ lse, float* __restrict__ pacc, float* __restrict__ pm, float* __restrict__ pl,
+    int O, int R, int L, long total_keys, int bits_stride, int n_split) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTile];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int split = blockIdx.x, rb = blockIdx.y, g = blockIdx.z;
+  const int o = g % O;
+  const int kh = lane >> 5;
+  FragBase fs = frag_base(lane);          // fragment bases of the ring stage being read (stage 0 first)
+  const int row = rb * 128 + wave * 32 + (lane & 31);
+  const bool row_ok = row < R;
+  int t0, t1;
+  split_range(n_tiles[o], n_split, split, t0, t1);
+
+  s16x8 qf[kKS];
+  load_row_frags(q + (static_cast<long>(g) * R + min(row, R - 1)) * kC, kh, qf);
+  f32x16 acc[kCT];
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;           // running maximum (log2 units) and this lane's part of the running sum
+  need_frags(qf);
+
+  const __amdgpu_buffer_rsrc_t krs = matrix_rsrc(k, total_keys), vrs = matrix_rsrc(v, total_keys);
+  const unsigned g_byte = static_cast<unsigned>(g) * static_cast<unsigned>(L) * kRowBytes;       // < 2^32: checked by the host
+  const unsigned* bits_o = keybits + static_cast<long>(o) * bits_stride;
+  if (t0 < t1) {
+    dma_tile(krs, g_byte + static_cast<unsigned>(t0) * kTile, lds, wave, lane);
+    dma_tile(vrs, g_byte + static_cast<unsigned>(t0) * kTile, lds + kTile, wave, lane);
+  }
+  dma_wait();
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int st = (t - t0) & 1;
+    if (t + 1 < t1) {
+      unsigned char* nx = lds + (st ^ 1) * 2 * kTile;
+      dma_tile(krs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx, wave, lane);
+      dma_tile(vrs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx + kTile, wave, lane);
+    }
+    // ---- S^T[key][row] = K Q^T
+    f32x16 sT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sT[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) sT = mfma(frag_rows<0>(lds, fs, ks), qf[ks], sT);
+    // ---- mask, online softmax (log2 units)
+    const unsigned bits = bits_o[t] >> (4 * kh);            // this lane's keys: (r & 3) + 8 (r >> 2) + 4 kh
+    float s2[16];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool masked = (bits >> ((r & 3) + 8 * (r >> 2))) & 1u;
+      s2[r] = masked ? -INFINITY : sT[r] * kLog2e;
+      mt = fmaxf(mt, s2[r]);
+    }
+    mt = fmaxf(mt, other_half(mt));
+    const float m_new = fmaxf(m_run, mt);
+    if (__any(m_new > m_run)) {
+      // the running maximum of some row grew: rescale the accumulator.  Through explicit accumulator-register moves:
+      // written as plain fp32 multiplies, the 192 accumulator values are allocated as arch VGPRs next to the 200 of
+      // the softmax / fragment code, and hipcc spills 84 registers around the tile loop.
+      const float alpha = m_new == -INFINITY ? 1.f : fast_exp2(m_run - m_new);     // m_run = -inf: exp2(-inf) = 0, acc is 0
+#pragma unroll
+      for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x;
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[ct][r]));
+          x *= alpha;
+          asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[ct][r]) : "v"(x));
+        }
+      l_run *= alpha;
+      m_run = m_new;
+    }
+    const float m_use = m_run == -INFINITY ? 0.f : m_run;
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = fast_exp2(s2[r] - m_use);
+      l_run += p[r];
+    }
+    s16x8 pf[2];
+    column_to_b_frags(p, pf);
+    // ---- O^T[channel][row] += V^T P^T
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[ct] = mfma(frag_cols<kTile>(lds, fs, j, ct), pf[j], acc[ct]);
+    frag_shift(fs, st ? -2 * kTile : 2 * kTile);
+    dma_wait();
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + other_half(l_run);
+  if (n_split == 1) {
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (row_ok) {
+      unsigned short* dst = ctx + (static_cast<long>(g) * R + row) * kC;
+#pragma unroll
+      for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const u32x2 w{pack_bf16(acc[ct][4 * qd] * inv, acc[ct][4 * qd + 1] * inv),
+                        pack_bf16(acc[ct][4 * qd + 2] * inv, acc[ct][4 * qd + 3] * inv)};
+          *reinterpret_cast<u32x2*>(dst + 32 * ct + 8 * qd + 4 * kh) = w;
+        }
+      if (kh == 0) lse[static_cast<long>(g) * R + row] = (m_run + log2f(l_tot)) * kLn2;
+    }
+  } else if (row_ok) {
+    const long prow = (static_cast<long>(g) * n_split + split) * R + row;
+    float* dst = pacc + prow * kC;
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        *reinterpret_cast<float4*>(dst + 32 * ct + 8 * qd + 4 * kh) =
+            float4{acc[ct][4 * qd], acc[ct][4 * qd + 1], acc[ct][4 * qd + 2], acc[ct][4 * qd + 3]};
+    if (kh == 0) {
+      pm[prow] = m_run;
+      pl[prow] = l_tot;
+    }
+  }
+}
+
+// partial results of the key splits -> ctx, lse.  One wave per (g, row); lane = 6 channels.
+__global__ __launch_bounds__(256) void roi_attn_fwd_combine(const float* __restrict__ pacc, const float* __restrict__ pm,
+                                                            const float* __restrict__ pl, unsigned short* __restrict__ ctx,
+                                                            float* __restrict__ lse, long n_rows, int R, int n_split) {
+  const long gr = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (gr >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const long g = gr / R;
+  const int row = static_cast<int>(gr - g * R);
+  float m = -INFINITY;
+  for (int s = 0; s < n_split; ++s) m = fmaxf(m, pm[(g * n_split + s) * R + row]);
+  float l = 0.f, a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < n_split; ++s) {
+    const long prow = (g * n_split + s) * R + row;
+    const float ms = pm[prow];
+    const float w = ms == -INFINITY ? 0.f : fast_exp2(ms - m);
+    l += pl[prow] * w;
+    const float2* src = reinterpret_cast<const float2*>(pacc + prow * kC + 6 * lane);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float2 x = src[i];
+      a[2 * i] += x.x * w;
+      a[2 * i + 1] += x.y * w;
+    }
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  unsigned* dst = reinterpret_cast<unsigned*>(ctx + gr * kC + 6 * lane);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dst[i] = pack_bf16(a[2 * i] * inv, a[2 * i + 1] * inv);
+  if (lane == 0) lse[gr] = (m + log2f(l)) * kLn2;
+}
+
+// ---------------------------------------------------------------------------
+// backward, query-stationary: dqf = dS k.  grid (n_split, row blocks of 128, G).  Also writes
+// dsum[g][row] = rowsum(dctx o ctx) (split 0) for the key-stationary kernel.
+// ---------------------------------------------------------------------------
+TRANSOAR_ATTN_KERNEL void roi_attn_bwd_q(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k, const unsigned short* __restrict__ v,
+    const unsigned short* __restrict__ ctx, const unsigned short* __restrict__ dctx, const float* __restrict__ lse,
+    const unsigned* __restrict__ keybits, const int* __restrict__ n_tiles, unsigned short* __restrict__ dq,
+    float* __restrict__ pdq, float* __restrict__ dsum, int O, int R, int L, long total_keys, int bits_stride, int n_split) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTile];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int split = blockIdx.x, rb = blockIdx.y, g = blockIdx.z;
+  const int o = g % O;
+  const int kh = lane >> 5;
+  FragBase fs = frag_base(lane);          // fragment bases of the ring stage being read (stage 0 first)
+  const int row = rb * 128 + wave * 32 + (lane & 31);
+  const bool row_ok = row < R;
+  const long grow = static_cast<long>(g) * R + min(row, R - 1);
+  int t0, t1;
+  split_range(n_tiles[o], n_split, split, t0, t1);
+
+  s16x8 qf[kKS], df[kKS];
+  load_row_frags(q + grow * kC, kh, qf);
+  load_row_frags(dctx + grow * kC, kh, df);
+  // D = rowsum(dctx o ctx): this lane's half of the channels, then the other half's
+  float dpart = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) {
+    const u32x4 c4 = *reinterpret_cast<const u32x4*>(ctx + grow * kC + 16 * ks + 8 * kh);
+    const u32x4 d4 = __builtin_bit_cast(u32x4, df[ks]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dpart += bf16_lo(c4[i]) * bf16_lo(d4[i]) + bf16_hi(c4[i]) * bf16_hi(d4[i]);
+  }
+  const float dsum_row = dpart + other_half(dpart);
+  if (split == 0 && row_ok && kh == 0) dsum[static_cast<long>(g) * R + row] = dsum_row;
+  float lse2 = row_ok ? lse[grow] * kLog2e : INFINITY;       // padding rows: P = 0
+  need(lse2);
+  need_frags(qf);
+  need_frags(df);
+  f32x16 acc[kCT];
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t krs = matrix_rsrc(k, total_keys), vrs = matrix_rsrc(v, total_keys);
+  const unsigned g_byte = static_cast<unsigned>(g) * static_cast<unsigned>(L) * kRowBytes;       // < 2^32: checked by the host
+  const unsigned* bits_o = keybits + static_cast<long>(o) * bits_stride;
+  if (t0 < t1) {
+    dma_tile(krs, g_byte + static_cast<unsigned>(t0) * kTile, lds, wave, lane);
+    dma_tile(vrs, g_byte + static_cast<unsigned>(t0) * kTile, lds + kTile, wave, lane);
+  }
+  dma_wait();
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int st = (t - t0) & 1;
+    if (t + 1 < t1) {
+      unsigned char* nx = lds + (st ^ 1) * 2 * kTile;
+      dma_tile(krs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx, wave, lane);
+      dma_tile(vrs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx + kTile, wave, lane);
+    }
+    f32x16 sT, dpT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) sT = mfma(frag_rows<0>(lds, fs, ks), qf[ks], sT);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) dpT = mfma(frag_rows<kTile>(lds, fs, ks), df[ks], dpT);
+    const unsigned bits = bits_o[t] >> (4 * kh);
+    unsigned dpk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float ds2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int r = 2 * i + e;
+        const bool masked = (bits >> ((r & 3) + 8 * (r >> 2))) & 1u;
+        const float pr = masked ? 0.f : fast_exp2(sT[r] * kLog2e - lse2);
+        ds2[e] = pr * (dpT[r] - dsum_row);
+      }
+      dpk[i] = pack_bf16(ds2[0], ds2[1]);
+    }
+    s16x8 dsf[2];
+    packed_column_to_b_frags(dpk, dsf);
+    // dQ^T[channel][row] += K^T dS^T
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[ct] = mfma(frag_cols<0>(lds, fs, j, ct), dsf[j], acc[ct]);
+    frag_shift(fs, st ? -2 * kTile : 2 * kTile);
+    dma_wait();
+    __syncthreads();
+  }
+  if (!row_ok) return;
+  if (n_split == 1) {
+    unsigned short* dst = dq + (static_cast<long>(g) * R + row) * kC;
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const u32x2 w{pack_bf16(acc[ct][4 * qd], acc[ct][4 * qd + 1]), pack_bf16(acc[ct][4 * qd + 2], acc[ct][4 * qd + 3])};
+        *reinterpret_cast<u32x2*>(dst + 32 * ct + 8 * qd + 4 * kh) = w;
+      }
+  } else {
+    float* dst = pdq + ((static_cast<long>(g) * n_split + split) * R + row) * kC;
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        *reinterpret_cast<float4*>(dst + 32 * ct + 8 * qd + 4 * kh) =
+            float4{acc[ct][4 * qd], acc[ct][4 * qd + 1], acc[ct][4 * qd + 2], acc[ct][4 * qd + 3]};
+  }
+}
+
+// sum of the key splits' partial dqf -> bf16.  One thread per 4 channels.
+__global__ __launch_bounds__(256) void roi_attn_sum_splits(const float* __restrict__ part, unsigned short* __restrict__ out,
+                                                           long n_rows, int R, int n_split) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;       // (g * R + row) * 96 + c4
+  if (i >= n_rows * (kC / 4)) return;
+  const long gr = i / (kC / 4);
+  const int c4 = static_cast<int>(i - gr * (kC / 4));
+  const long g = gr / R;
+  const int row = static_cast<int>(gr - g * R);
+  float4 a{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < n_split; ++s) {
+    const float4 x = *reinterpret_cast<const float4*>(part + ((g * n_split + s) * R + row) * kC + 4 * c4);
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+  }
+  *reinterpret_cast<u32x2*>(out + gr * kC + 4 * c4) = u32x2{pack_bf16(a.x, a.y), pack_bf16(a.z, a.w)};
+}
+
+// ---------------------------------------------------------------------------
+// backward, key-stationary: dtok = dS^T qf + P^T dctx.  grid (key blocks of 128, G); a wave owns 32 keys.
+// ---------------------------------------------------------------------------
+TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k, const unsigned short* __restrict__ v,
+    const unsigned short* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ dsum,
+    const unsigned* __restrict__ keybits, const int* __restrict__ n_tiles, unsigned short* __restrict__ dtok,
+    int O, int R, int L, long total_rows, int bits_stride) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTile + kMaxRowTiles * 256];
+  float* stats = reinterpret_cast<float*>(lds + 4 * kTile);       // [row tile][lse2 x 32 | dsum x 32]: all of the group's rows, loaded once
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int kb = blockIdx.x, g = blockIdx.y;
+  const int o = g % O;
+  const int kh = lane >> 5;
+  FragBase fs = frag_base(lane);          // fragment bases of the ring stage being read (stage 0 first)
+  const int key0 = kb * 128 + wave * 32;
+  const int key = key0 + (lane & 31);
+  unsigned short* out_g = dtok + static_cast<long>(g) * L * kC;
+  if (kb * 4 >= n_tiles[o]) {
+    // every key of the block is padding: its token gradient is zero
+    for (int i = threadIdx.x; i < 128 * (kC / 8); i += 256) {
+      const int kk = kb * 128 + i / (kC / 8);
+      if (kk < L) *reinterpret_cast<u32x4*>(out_g + static_cast<long>(kk) * kC + 8 * (i % (kC / 8))) = u32x4{0u, 0u, 0u, 0u};
+    }
+    return;
+  }
+  const long gkey = static_cast<long>(g) * L + min(key, L - 1);
+  s16x8 kf[kKS], vf[kKS];
+  load_row_frags(k + gkey * kC, kh, kf);
+  load_row_frags(v + gkey * kC, kh, vf);
+  const unsigned bits_w = key0 < L ? keybits[static_cast<long>(o) * bits_stride + (key0 >> 5)] : 0xffffffffu;
+  int masked_i = (bits_w >> (lane & 31)) & 1u;
+  need(masked_i);
+  const bool masked = masked_i != 0;
+  need_frags(kf);
+  need_frags(vf);
+  f32x16 acc[kCT];
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t qrs = matrix_rsrc(q, total_rows), drs = matrix_rsrc(dctx, total_rows);
+  const unsigned g_byte = static_cast<unsigned>(g) * static_cast<unsigned>(R) * kRowBytes;
+  const int n_rt = (R + 31) >> 5;
+  // lse (log2 units) and rowsum(dctx o ctx) of every row of the group -> LDS, before the tile loop (a vector memory
+  // load inside the loop would make hipcc wait for the loop's DMA with it)
+  for (int i = threadIdx.x; i < n_rt * 64; i += 256) {
+    const int rr = (i >> 6) * 32 + (i & 31);
+    float x;
+    if ((i & 32) == 0) x = rr < R ? lse[static_cast<long>(g) * R + rr] * kLog2e : INFINITY;       // padding rows: P = 0
+    else x = rr < R ? dsum[static_cast<long>(g) * R + rr] : 0.f;
+    stats[i] = x;
+  }
+  dma_tile(qrs, g_byte, lds, wave, lane);
+  dma_tile(drs, g_byte, lds + kTile, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int rt = 0; rt < n_rt; ++rt) {
+    const int st = rt & 1;
+    if (rt + 1 < n_rt) {
+      unsigned char* nx = lds + (st ^ 1) * 2 * kTile;
+      dma_tile(qrs, g_byte + static_cast<unsigned>(rt + 1) * kTile, nx, wave, lane);
+      dma_tile(drs, g_byte + static_cast<unsigned>(rt + 1) * kTile, nx + kTile, wave, lane);
+    }
+    // S[row][key] = Q K^T and dP[row][key] = dctx V^T: lane = (key, half), register r = row (r & 3) + 8 (r >> 2) + 4 kh
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) s = mfma(frag_rows<0>(lds, fs, ks), kf[ks], s);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) dp = mfma(frag_rows<kTile>(lds, fs, ks), vf[ks], dp);
+    unsigned ppk[8], dpk[8];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 l4 = *reinterpret_cast<const float4*>(stats + rt * 64 + 8 * qd + 4 * kh);
+      const float4 d4 = *reinterpret_cast<const float4*>(stats + rt * 64 + 32 + 8 * qd + 4 * kh);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+      float pr[4], dsr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * qd + i;
+        pr[i] = masked ? 0.f : fast_exp2(s[r] * kLog2e - ls[i]);
+        dsr[i] = pr[i] * (dp[r] - dd[i]);
+      }
+      ppk[2 * qd] = pack_bf16(pr[0], pr[1]); ppk[2 * qd + 1] = pack_bf16(pr[2], pr[3]);
+      dpk[2 * qd] = pack_bf16(dsr[0], dsr[1]); dpk[2 * qd + 1] = pack_bf16(dsr[2], dsr[3]);
+    }
+    s16x8 pf[2], dsf[2];
+    packed_column_to_b_frags(ppk, pf);
+    packed_column_to_b_frags(dpk, dsf);
+    // dTok^T[channel][key] += Q^T dS + dctx^T P
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[ct] = mfma(frag_cols<0>(lds, fs, j, ct), dsf[j], acc[ct]);
+        acc[ct] = mfma(frag_cols<kTile>(lds, fs, j, ct), pf[j], acc[ct]);
+      }
+    frag_shift(fs, st ? -2 * kTile : 2 * kTile);
+    dma_wait();
+    __syncthreads();
+  }
+  // ---- the wave's 32 x 384 result -> LDS [key][channel] bf16 -> whole 768-byte rows
+  unsigned char* ob = lds + wave * kTile;
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      *reinterpret_cast<u32x2*>(ob + (lane & 31) * kRowBytes + (32 * ct + 8 * qd + 4 * kh) * 2) =
+          u32x2{pack_bf16(acc[ct][4 * qd], acc[ct][4 * qd + 1]), pack_bf16(acc[ct][4 * qd + 2], acc[ct][4 * qd + 3])};
+  // (a wave's LDS operations execute in order: its reads below see its writes above; no other wave touches this region)
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const int off = i * 1024 + lane * 16;
+    const int kr = ((off >> 8) * 171) >> 9;
+    if (key0 + kr < L)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(out_g + static_cast<long>(key0) * kC) + off) =
+          *reinterpret_cast<const u32x4*>(ob + off);
+  }
+}
+
+}  // namespace transoar
+
+using namespace transoar;
+
+static inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+extern "C" size_t transoar_roi_attn_workspace_bytes(int G, int R, int n_split) {
+  if (G <= 0 || R <= 0 || n_split < 1) return 0;
+  const size_t rows = static_cast<size_t>(G) * R;
+  size_t bytes = align256(rows * sizeof(float));                                  // dsum
+  if (n_split > 1) bytes += align256(rows * n_split * kC * sizeof(float)) + 2 * align256(rows * n_split * sizeof(float));
+  return bytes;
+}
+
+static int check_common(const void* q, const void* k, const void* v, const void* bits, const void* nt, int G, int O, int R,
+                        long L, int C, int n_split) {
+  if (!q || !k || !v || !bits || !nt) return TRANSOAR_ATTN_ERR_NULL;
+  if (C != kC || G <= 0 || O <= 0 || G % O != 0 || R <= 0 || R > 32 * kMaxRowTiles || L <= 0 || n_split < 1 || n_split > 64) return TRANSOAR_ATTN_ERR_DIM;
+  // tiles are addressed with 32-bit byte offsets into k / v / q / dctx
+  if ((static_cast<long>(G) * L + 64) * kRowBytes >= 0x7fffffffL || (static_cast<long>(G) * R + 64) * kRowBytes >= 0x7fffffffL || G >= 65536)
+    return TRANSOAR_ATTN_ERR_DIM;
+  return TRANSOAR_ATTN_OK;
+}
+
+extern "C" int transoar_roi_attn_forward(const void* q, const void* k, const void* v, const unsigned* keybits, const int* n_tiles,
+                                         void* ctx, float* lse, void* workspace, size_t workspace_bytes, int G, int O, int R, long L,
+                                         int C, int n_split, void* hip_stream) {
+  int rc = check_common(q, k, v, keybits, n_tiles, G, O, R, L, C, n_split);
+  if (rc != TRANSOAR_ATTN_OK) return rc;
+  if (!ctx || !lse) return TRANSOAR_ATTN_ERR_NULL;
+  if (workspace_bytes < transoar_roi_attn_workspace_bytes(G, R, n_split) || (n_split > 1 && !workspace)) return TRANSOAR_ATTN_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const size_t rows = static_cast<size_t>(G) * R;
+  char* ws = static_cast<char*>(workspace);
+  float* pacc = nullptr; float* pm = nullptr; float* pl = nullptr;
+  if (n_split > 1) {
+    pacc = reinterpret_cast<float*>(ws + align256(rows * sizeof(float)));
+    pm = reinterpret_cast<float*>(reinterpret_cast<char*>(pacc) + align256(rows * n_split * kC * sizeof(float)));
+    pl = reinterpret_cast<float*>(reinterpret_cast<char*>(pm) + align256(rows * n_split * sizeof(float)));
+  }
+  const int bits_stride = static_cast<int>((L + 31) / 32);
+  const dim3 grid(n_split, (R + 127) / 128, G);
+  hipLaunchKernelGGL(roi_attn_fwd, grid, dim3(256), 0, st, static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k),
+                     static_cast<const unsigned short*>(v), keybits, n_tiles, static_cast<unsigned short*>(ctx), lse, pacc, pm, pl, O, R,
+                     static_cast<int>(L), static_cast<long>(G) * L, bits_stride, n_split);
+  if (n_split > 1)
+    hipLaunchKernelGGL(roi_attn_fwd_combine, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, st, pacc, pm, pl,
+                       static_cast<unsigned short*>(ctx), lse, static_cast<long>(rows), R, n_split);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_roi_attn_backward(const void* q, const void* k, const void* v, const void* ctx, const void* dctx, const float* lse,
+                                          const unsigned* keybits, const int* n_tiles, void* dq, void* dtok, void* workspace,
+                                          size_t workspace_bytes, int G, int O, int R, long L, int C, int n_split, void* hip_stream) {
+  int rc = check_common(q, k, v, keybits, n_tiles, G, O, R, L, C, n_split);
+  if (rc != TRANSOAR_ATTN_OK) return rc;
+  if (!ctx || !dctx || !lse || !dq || !dtok || !workspace) return TRANSOAR_ATTN_ERR_NULL;
+  if (workspace_bytes < transoar_roi_attn_workspace_bytes(G, R, n_split)) return TRANSOAR_ATTN_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const size_t rows = static_cast<size_t>(G) * R;
+  char* ws = static_cast<char*>(workspace);
+  float* dsum = reinterpret_cast<float*>(ws);
+  float* pdq = n_split > 1 ? reinterpret_cast<float*>(ws + align256(rows * sizeof(float))) : nullptr;
+  const int bits_stride = static_cast<int>((L + 31) / 32);
+  auto qs = static_cast<const unsigned short*>(q);
+  auto ks = static_cast<const unsigned short*>(k);
+  auto vs = static_cast<const unsigned short*>(v);
+  auto ds = static_cast<const unsigned short*>(dctx);
+  hipLaunchKernelGGL(roi_attn_bwd_q, dim3(n_split, (R + 127) / 128, G), dim3(256), 0, st, qs, ks, vs,
+                     static_cast<const unsigned short*>(ctx), ds, lse, keybits, n_tiles, static_cast<unsigned short*>(dq), pdq, dsum, O, R,
+                     static_cast<int>(L), static_cast<long>(G) * L, bits_stride, n_split);
+  if (n_split > 1)
+    hipLaunchKernelGGL(roi_attn_sum_splits, dim3(static_cast<unsigned>((rows * (kC / 4) + 255) / 256)), dim3(256), 0, st, pdq,
+                       static_cast<unsigned short*>(dq), static_cast<long>(rows), R, n_split);
+  hipLaunchKernelGGL(roi_attn_bwd_k, dim3(static_cast<unsigned>((L + 127) / 128), G), dim3(256), 0, st, qs, ks, vs, ds, lse, dsum, keybits,
+                     n_tiles, static_cast<unsigned short*>(dtok), O, R, static_cast<int>(L), static_cast<long>(G) * R, bits_stride);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_attn_abi_version(void) { return 1; }

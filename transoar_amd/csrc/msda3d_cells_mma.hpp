@@ -60,31 +60,43 @@ __device__ __forceinline__ void cell_run_mma(
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   // one K-step = 16 points: their records (256 contiguous bytes; the four lanes that fetch a point's grad_out row
-  // all read its whole 16-byte record -- one request per quad) and grad_out rows, staged one step ahead.
-  u32x4 rec_pre;
-  u32x4 row_pre[2];
-  auto issue = [&](int s) {
-    const int pr = min(s + (lane >> 2), last);
-    rec_pre = *reinterpret_cast<const u32x4*>(recs + pr);
-    const long item = static_cast<int>(rec_pre.y);
-    const u32x4* src = reinterpret_cast<const u32x4*>(grad_out + item * C);
-    row_pre[0] = src[st_q];
-    row_pre[1] = src[4 + st_q];
+  // all read its whole 16-byte record -- one request per quad) and their grad_out rows.  The row address depends on
+  // the record, i.e. two memory latencies in series per step: records are requested THREE steps ahead and rows TWO,
+  // so that neither wait is exposed once a run is under way (one step ahead for both, a step paid the record's
+  // latency in full: the walks were 65 % wait cycles).
+  auto load_rec = [&](int s) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(recs + min(s + (lane >> 2), last));
   };
-  issue(t);
+  auto load_rows = [&](const u32x4& rec, u32x4 (&rows)[2]) {
+    const long item = static_cast<int>(rec.y);
+    const u32x4* src = reinterpret_cast<const u32x4*>(grad_out + item * C);
+    rows[0] = src[st_q];
+    rows[1] = src[4 + st_q];
+  };
+  u32x4 rec0 = load_rec(t), rec1 = rec0, rec2 = rec0;       // records of steps s, s + 16, s + 32
+  if (t + 16 < t_end) rec1 = load_rec(t + 16);
+  if (t + 32 < t_end) rec2 = load_rec(t + 32);
+  u32x4 row0[2], row1[2];                                    // grad_out rows of steps s, s + 16
+  load_rows(rec0, row0);
+  row1[0] = row0[0]; row1[1] = row0[1];
+  if (t + 16 < t_end) load_rows(rec1, row1);
   for (int s = t; s < t_end; s += 16) {
     if ((lane & 2) == 0) {
       // lanes 0 / 1 of a quad expand the record into the weights of dd = 0 / 1: [t (1 - lw), t lw] per dh
       float ld, lh, lw;
-      point_r16_fracs(rec_pre.z, rec_pre.w, ld, lh, lw);
-      const float td = __uint_as_float(rec_pre.x) * ((lane & 1) ? ld : 1.f - ld);
+      point_r16_fracs(rec0.z, rec0.w, ld, lh, lw);
+      const float td = __uint_as_float(rec0.x) * ((lane & 1) ? ld : 1.f - ld);
       const float tb = td * lh, ta = td - tb;
       const float ya = ta * lw, yb = tb * lw;
       *reinterpret_cast<float4*>(wrec + (lane >> 2) * 8 + (lane & 1) * 4) = float4{ta - ya, ya, tb - yb, yb};
     }
-    *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + st_q * 16) = row_pre[0];
-    *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + 64 + st_q * 16) = row_pre[1];
-    if (s + 16 < t_end) issue(s + 16);
+    *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + st_q * 16) = row0[0];
+    *reinterpret_cast<u32x4*>(vrow + st_row * kCmRowPitch + 64 + st_q * 16) = row0[1];
+    // rotate the pipeline: rows of step s + 32 (their records arrived a step ago), records of step s + 48
+    rec0 = rec1; rec1 = rec2;
+    row0[0] = row1[0]; row0[1] = row1[1];
+    if (s + 32 < t_end) load_rows(rec1, row1);
+    if (s + 48 < t_end) rec2 = load_rec(s + 48);
     // ---- A: this lane's voxel row x points s + 8 kg .. + 7
     float wa[8];
 #pragma unroll

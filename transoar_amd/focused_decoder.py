@@ -30,7 +30,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import rows, shadow
+from . import roi_attn, rows, shadow
 from . import tokens as fused_tokens
 from .position_encoding import is_constant
 from .token_linear import token_linear
@@ -234,8 +234,13 @@ class FocusedAttn(nn.Module):
         qf = torch.einsum("boqhd,hdc->bohqc", qq, w_k).reshape(b, n_org, h * qpo, c)        # Wk_h^T q_h
         if keys_follow_values and k_tok.dtype == qf.dtype and v_tok.dtype == qf.dtype:
             # k = v + constant positions: one token gradient (see _FoldedCore)
+            k4, v4 = k_tok.detach().view(b, n_org, n_keys, c), v_tok.view(b, n_org, n_keys, c)
             with torch.autocast(q.device.type, enabled=False):
-                ctx = _FoldedCore.apply(qf, k_tok.detach().view(b, n_org, n_keys, c), v_tok.view(b, n_org, n_keys, c), pad)
+                if roi_attn.usable(qf, k4, v4):
+                    # QK^T -> RoI mask -> softmax -> PV in one hand-written kernel, backward recomputes P (csrc/attn.hip)
+                    ctx = roi_attn.roi_attention(qf, k4, v4, pad)
+                else:
+                    ctx = _FoldedCore.apply(qf, k4, v4, pad)
             ctx = ctx.view(b, n_org, h, qpo, c)
         else:
             scores = _Scores.apply(qf, k_tok.view(b, n_org, n_keys, c).to(qf.dtype))             # (B, O, h*qpo, L)
