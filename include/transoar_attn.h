@@ -45,6 +45,25 @@ int transoar_roi_attn_backward(const void* q, const void* k, const void* v, cons
                                void* workspace, size_t workspace_bytes, int G, int O, int R, long L, int C, int n_split,
                                void* hip_stream);
 
+/*
+ * Swin 3-D window attention (transoar/models/backbones/encoder_blocks.py:56-140):
+ * per (window, head):  out = softmax(scale q k^T + bias[head] + mask[window % n_win]) v.
+ *   qkv      (windows, n, 3, heads, 32) bf16: the output of the block's qkv projection, as it lies in memory
+ *   bias     (heads, n, 128) fp32: relative-position bias, key axis padded to 128 (entries >= n are not read ... but the
+ *            row must be addressable)
+ *   maskbits (n_win, n, 4) uint32 or NULL: bit (key % 32) of word (key / 32) = the region labels of (row, key) differ,
+ *            i.e. the reference's additive -100 (encoder_blocks.py:373-386); window w uses entry w % n_win
+ *   out      (windows, n, heads * 32) bf16;  lse2 (windows, heads, n) fp32: log2-sum-exp2 of the rows (for the backward)
+ * backward: dqkv (windows, n, 3, heads, 32) bf16 fully written; dbias (heads, n, 128) fp32 is ACCUMULATED into
+ * (the caller zeroes it): the sum of dS over the windows.
+ * n <= 128, head dimension 32.
+ */
+int transoar_win_attn_forward(const void* qkv, const float* bias, const unsigned* maskbits, void* out, float* lse2,
+                              int windows, int n_win, int n, int heads, int head_dim, float scale, void* hip_stream);
+int transoar_win_attn_backward(const void* qkv, const void* out, const void* dout, const float* lse2, const float* bias,
+                               const unsigned* maskbits, void* dqkv, float* dbias, int windows, int n_win, int n, int heads,
+                               int head_dim, float scale, void* hip_stream);
+
 int transoar_attn_abi_version(void);
 
 #ifdef __cplusplus

@@ -17,6 +17,7 @@ no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
     python tests/golden/make_golden.py            # rewrites the op/module fixtures g1..g5
     python tests/golden/make_golden.py --models   # additionally g6 (backbone), g7 (whole model)
     python tests/golden/make_golden.py --swin     # only g8 (Swin encoder backbone)
+    python tests/golden/make_golden.py --swin-stage   # only g9 (one full-width Swin stage: head dimension 32)
 
 g6/g7 import the reference's full model, which needs two container-only shims
 (a stub ``timm.models.layers`` and ``Tensor.cuda = identity``).
@@ -326,6 +327,40 @@ def g8_swin_backbone():
         store[tag + ".grad_abs_sums"] = np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads])
     np.savez_compressed(os.path.join(HERE, "g8_swin_backbone.npz"), **store)
 
+
+def g9_swin_stage():
+    """One Swin stage at the flagship WIDTH of encoder stage 2 (96 channels, 3 heads of 32, 5x5x5 windows, depth 2: a
+    plain and a shifted-window block, no patch merge) on a 7x6x11 grid (padding on all three axes, 12 windows of 125
+    tokens, shifted-window mask): the shape class the hand-written window-attention kernel serves (head dimension 32),
+    which the reduced-width g8 model (head dimension 8) cannot reach.  Input, output, input gradient and the parameter
+    gradients of sum(y * g) for a fixed g."""
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import fill_deterministic
+    from transoar.models.backbones.encoder_blocks import EncoderSwinBlock
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(1, 96, 7, 6, 11, generator=gen).requires_grad_()
+    g = torch.randn(1, 96, 7, 6, 11, generator=gen)
+    stage = EncoderSwinBlock(dim=96, depth=2, num_heads=3, window_size=(5, 5, 5), mlp_ratio=4, qkv_bias=True, qk_scale=None,
+                             drop=0.0, attn_drop=0.0, drop_path=0.0, downsample=None).eval()
+    fill_deterministic(stage)
+    with torch.no_grad():                    # a non-trivial relative-position bias (fill_deterministic leaves buffers alone)
+        for blk in stage.blocks:
+            t = blk.attn.relative_position_bias_table
+            t.copy_(0.3 * torch.sin(torch.arange(t.numel(), dtype=torch.float32).view_as(t) * 0.37))
+    y = stage(x)
+    params = dict(stage.named_parameters())
+    grads = torch.autograd.grad((y * g).sum(), [x] + list(params.values()))
+    store = {"x": x.detach().numpy(), "g": g.numpy(), "y": y.detach().numpy(), "dx": grads[0].numpy(),
+             "state_names": np.array(list(stage.state_dict().keys())), "grad_names": np.array(list(params.keys()))}
+    for name, gr in zip(params, grads[1:]):
+        store["grad." + name] = gr.numpy()
+    np.savez_compressed(os.path.join(HERE, "g9_swin_stage.npz"), **store)
+
+
+if __name__ == "__main__" and "--swin-stage" in sys.argv:
+    g9_swin_stage()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--swin" in sys.argv:
     g8_swin_backbone()

@@ -208,4 +208,4 @@ def test_roi_attention_argument_errors():
     b.argtypes = [p] * 11 + [z, i, i, i, lg, i, i, p]
     assert b(p16, p16, p16, p16, p16, p16, p16, p16, None, p16, p16, 1 << 20, 1, 1, 8, 32, 384, 1, None) == -1
     assert b(p16, p16, p16, p16, p16, p16, p16, p16, p16, p16, p16, 16, 1, 1, 8, 32, 384, 1, None) == -3
-    assert lib.transoar_attn_abi_version() == 1
+    assert lib.transoar_attn_abi_version() == 2

@@ -312,6 +312,60 @@ def test_g8_swin_encoder_backbone(golden_dir, debug_core, device, tag, conv_merg
         assert abs(got - s) <= gtol * max(a, 1e-6) + 2e-6, name
 
 
+def _g9_stage(golden_dir):
+    from transoar_amd.swin_encoder import EncoderSwinBlock
+    z = np.load(os.path.join(golden_dir, "g9_swin_stage.npz"))
+    stage = EncoderSwinBlock(dim=96, depth=2, num_heads=3, window_size=(5, 5, 5), mlp_ratio=4, qkv_bias=True, qk_scale=None,
+                             drop=0.0, attn_drop=0.0, drop_path=0.0, downsample=None).eval()
+    assert list(stage.state_dict().keys()) == list(z["state_names"])
+    fill_deterministic(stage)
+    with torch.no_grad():
+        for blk in stage.blocks:
+            t = blk.attn.relative_position_bias_table
+            t.copy_(0.3 * torch.sin(torch.arange(t.numel(), dtype=torch.float32).view_as(t) * 0.37))
+    return z, stage
+
+
+def test_g9_full_width_swin_stage_fp32(golden_dir):
+    """One Swin stage at stage 2's flagship width (96 channels, 3 heads of 32, two blocks: plain + shifted windows) on a
+    7x6x11 grid against the reference's EncoderSwinBlock (tests/golden/make_golden.py:g9_swin_stage): the plain torch
+    formulation in fp32, CPU."""
+    z, stage = _g9_stage(golden_dir)
+    x = torch.from_numpy(z["x"]).requires_grad_()
+    y = stage(x)
+    assert relerr(y, z["y"]) <= 1e-5
+    params = dict(stage.named_parameters())
+    grads = torch.autograd.grad((y * torch.from_numpy(z["g"])).sum(), [x] + list(params.values()))
+    assert relerr(grads[0], z["dx"]) <= 1e-4
+    for name, g in zip(params, grads[1:]):
+        assert relerr(g, z["grad." + name]) <= 1e-4, name
+
+
+@pytest.mark.gpu
+def test_g9_full_width_swin_stage_on_the_kernels(golden_dir, monkeypatch):
+    """The same stage under bf16 autocast on the GPU: window partition / merge on the row kernels, the projections and
+    the MLP on the hand-written GEMMs, attention on the window-attention kernel (checked: it is called once per block each
+    way) -- against the reference's fp32 numbers at bf16 tolerances."""
+    _skip_if_no_gpu("cuda")
+    from transoar_amd import swin_encoder, win_attn
+    z, stage = _g9_stage(golden_dir)
+    stage = stage.cuda()
+    calls = []
+    real = win_attn.window_attention
+    monkeypatch.setattr(swin_encoder, "MIN_TOKENS", 0)          # 462 tokens: take the GEMM kernels anyway
+    monkeypatch.setattr(win_attn, "window_attention", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = torch.from_numpy(z["x"]).cuda().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = stage(x)
+    assert len(calls) == 2, calls
+    assert relerr(y, z["y"]) <= 2.0 ** -6, relerr(y, z["y"])
+    params = dict(stage.named_parameters())
+    grads = torch.autograd.grad((y.float() * torch.from_numpy(z["g"]).cuda()).sum(), [x] + list(params.values()))
+    assert relerr(grads[0], z["dx"]) <= 2.0 ** -5, relerr(grads[0], z["dx"])
+    for name, g in zip(params, grads[1:]):
+        assert relerr(g, z["grad." + name]) <= 3e-2, (name, relerr(g, z["grad." + name]))
+
+
 def test_swin_stochastic_depth_and_window_layout():
     """DropPath drops whole samples with probability p and rescales the survivors; the one-gather window
     layout equals pad + roll + partition written out."""

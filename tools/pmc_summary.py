@@ -9,7 +9,8 @@ SHORT = [("msda3d_fwd_pcm", "fwd_pcm"), ("msda3d_fwd_mma", "fwd_mma"), ("msda3d_
          ("msda3d_cell_fill_w8", "cell_fill_w8"), ("msda3d_bwd_value_tile", "bwd_value_tile"),
          ("msda3d_bwd_value_cells", "bwd_value_cells"), ("msda3d_coarse_rows_store", "coarse_rows_store"),
          ("msda3d_scan_tiles", "scan_tiles"), ("msda3d_fwd_vec", "fwd_vec"), ("msda3d_bwd_query_vec", "bwd_query_vec"),
-         ("msda3d_bwd_value_pull", "value_pull"), ("msda3d_cell_fill", "cell_fill"), ("msda3d_cell_count", "cell_count")]
+         ("msda3d_bwd_value_pull", "value_pull"), ("msda3d_cell_fill", "cell_fill"), ("msda3d_cell_count", "cell_count"),
+         ("msda3d_scan_add", "scan_add"), ("msda3d_scan_tile_sums", "scan_tile_sums"), ("msda3d_zero16", "zero16")]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     per_dispatch = collections.defaultdict(float)

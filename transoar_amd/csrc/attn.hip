@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/transoar_attn.h"
 
 namespace transoar {
@@ -629,6 +631,298 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
   }
 }
 
+// ===========================================================================
+// Swin 3-D window attention (transoar/models/backbones/encoder_blocks.py:56-140,
+// WindowAttention3D): per (window, head)
+//     S = scale q k^T + relative-position bias[head] + shifted-window mask[window]      (n <= 128 tokens, head dim 32)
+//     out = softmax(S) v
+// Round 3 ran this on torch SDPA with a dense additive mask (the fp32 math path: six fp32 batched GEMMs, softmax,
+// isneginf / where / reduce passes over (windows, heads, n, n) tensors).  Here one workgroup owns a (window, head):
+// K and V (128 x 32) sit in LDS, a wave owns 32 query rows and holds all their 128 scores in registers (exact
+// softmax, no running maximum), bias rows are read as aligned float4 (the host pads the key axis to 128), the mask is
+// one bit per (row, key) ("region labels differ").  The backward kernel is persistent over the windows of a head so
+// that the bias gradient accumulates in registers and reaches memory once per workgroup.
+// Tiles [rows][32 channels] keep their four 16-byte pieces at piece ^ ((row >> 2) & 3): conflict-free for the
+// ds_read_b128 operand fragments, and a transposing read's four rows still tile the 64 banks.
+// ===========================================================================
+constexpr int kWinHd = 32;                 // head dimension
+constexpr int kWinN = 128;                 // tokens of a window, padded
+constexpr int kWinTile = kWinN * kWinHd * 2;      // 8 KiB
+constexpr int kWinPPitch = 320;            // bytes per row of the P / dS tiles (256 + 64: four rows of a transposing read tile the banks)
+
+__device__ __forceinline__ int w32_off(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
+// rows [r0, r0 + 32) of a [rows][32] tile as an MFMA operand [32 rows][16 channels of K step ks]
+__device__ __forceinline__ s16x8 w32_rows(const unsigned char* tile, int lane, int r0, int ks) {
+  return *reinterpret_cast<const s16x8*>(tile + w32_off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
+}
+// the transposed tile as an MFMA operand [32 channels][16 rows R0 + 8 kh .. + 7]
+__device__ __forceinline__ s16x8 w32_cols(const unsigned char* tile, int lane, int R0) {
+  const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
+  const int n0 = R0 + 8 * kh + r, n1 = n0 + 4;
+  const int p = 2 * g + (c >> 1);
+  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + w32_off(n0, p) + 8 * (c & 1)));
+  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + w32_off(n1, p) + 8 * (c & 1)));
+  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// a [row][key] tile (pitch kWinPPitch) as the MFMA B operand [k = rows R0 + 8 kh .. + 7][n = key K0 + (lane & 31)]
+__device__ __forceinline__ s16x8 wp_frag(const unsigned char* tile, int lane, int R0, int K0) {
+  const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
+  const unsigned char* a = tile + (R0 + 8 * kh + r) * kWinPPitch + 2 * K0 + 32 * g + 8 * c;
+  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * kWinPPitch));
+  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// one (window, head) slice [n tokens][32 channels] of the qkv tensor (tokens `tok_elems` elements apart) -> LDS tile;
+// rows >= n are zero.  256 threads: thread = (row, half of the row).
+__device__ __forceinline__ void win_load_tile(const unsigned short* __restrict__ src, long tok_elems, int n, unsigned char* tile) {
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  u32x4 a{0u, 0u, 0u, 0u}, b{0u, 0u, 0u, 0u};
+  if (row < n) {
+    const u32x4* g = reinterpret_cast<const u32x4*>(src + row * tok_elems + 16 * half);
+    a = g[0];
+    b = g[1];
+  }
+  *reinterpret_cast<u32x4*>(tile + w32_off(row, 2 * half)) = a;
+  *reinterpret_cast<u32x4*>(tile + w32_off(row, 2 * half + 1)) = b;
+}
+
+// scores of the wave's 32 rows against key tile t, in log2 units, masked: lane = (row i, half kh), entry r = key
+// 32 t + (r & 3) + 8 (r >> 2) + 4 kh
+__device__ __forceinline__ void win_scores(const f32x16& sT, int t, int kh, int n, float scale2, const float* __restrict__ bias_row,
+                                           unsigned mask_word, bool row_ok, float (&s2)[16]) {
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int key0 = 32 * t + 8 * qd + 4 * kh;
+    float4 b4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok) b4 = *reinterpret_cast<const float4*>(bias_row + key0);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * qd + e;
+      const bool differ = (mask_word >> (8 * qd + 4 * kh + e)) & 1u;
+      float v = sT[r] * scale2 + (bb[e] + (differ ? -100.f : 0.f)) * kLog2e;
+      s2[r] = (key0 + e < n) ? v : -INFINITY;
+    }
+  }
+}
+
+// forward: grid (windows, heads)
+__global__ __launch_bounds__(256) void win_attn_fwd(
+    const unsigned short* __restrict__ qkv, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
+    unsigned short* __restrict__ out, float* __restrict__ lse2, int n, int heads, int n_win, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kWinTile];
+  unsigned char* kt = lds;
+  unsigned char* vt = lds + kWinTile;
+  const int w = blockIdx.x, head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int kh = lane >> 5;
+  const long tok = 3L * heads * kWinHd;                                   // elements per token of qkv
+  const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * kWinHd;
+  win_load_tile(base + heads * kWinHd, tok, n, kt);
+  win_load_tile(base + 2 * heads * kWinHd, tok, n, vt);
+  const int i = wave * 32 + (lane & 31);
+  const bool row_ok = i < n;
+  s16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    u32x4 x{0u, 0u, 0u, 0u};
+    if (row_ok) x = *reinterpret_cast<const u32x4*>(base + i * tok + 16 * ks + 8 * kh);
+    qf[ks] = __builtin_bit_cast(s16x8, x);
+  }
+  u32x4 mw{0u, 0u, 0u, 0u};
+  if (maskbits != nullptr && row_ok) mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
+  const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
+  __syncthreads();
+  if (wave * 32 >= n) return;                          // no live row in this wave (n <= 96)
+
+  const float scale2 = scale * kLog2e;
+  float s2[4][16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x16 sT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sT[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) sT = mfma(w32_rows(kt, lane, 32 * t, ks), qf[ks], sT);
+    win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2[t]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, s2[t][r]);
+  }
+  m = fmaxf(m, other_half(m));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s2[t][r] = fast_exp2(s2[t][r] - m);
+      l += s2[t][r];
+    }
+  l += other_half(l);
+  const float inv = 1.f / l;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = s2[t][r] * inv;
+    s16x8 pf[2];
+    column_to_b_frags(p, pf);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc = mfma(w32_cols(vt, lane, 32 * t + 16 * j), pf[j], acc);
+  }
+  if (row_ok) {
+    unsigned short* dst = out + (static_cast<long>(w) * n + i) * (heads * kWinHd) + head * kWinHd;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      *reinterpret_cast<u32x2*>(dst + 8 * qd + 4 * kh) =
+          u32x2{pack_bf16(acc[4 * qd], acc[4 * qd + 1]), pack_bf16(acc[4 * qd + 2], acc[4 * qd + 3])};
+    if (kh == 0) lse2[(static_cast<long>(w) * heads + head) * n + i] = m + log2f(l);
+  }
+}
+
+// backward: grid (persistent workgroups, heads); workgroup x walks the windows x, x + gridDim.x, ... of its head
+__global__ __launch_bounds__(256) void win_attn_bwd(
+    const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ out, const unsigned short* __restrict__ dout,
+    const float* __restrict__ lse2, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
+    unsigned short* __restrict__ dqkv, float* __restrict__ dbias, int n, int heads, int n_win, int windows, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWinTile + 2 * kWinN * kWinPPitch];
+  unsigned char* kt = lds;
+  unsigned char* vt = lds + kWinTile;
+  unsigned char* qt = lds + 2 * kWinTile;
+  unsigned char* dt = lds + 3 * kWinTile;
+  unsigned char* pt = lds + 4 * kWinTile;                       // P   [row][key] bf16
+  unsigned char* st = pt + kWinN * kWinPPitch;                  // scale * dS [row][key] bf16
+  const int head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int kh = lane >> 5;
+  const long tok = 3L * heads * kWinHd;
+  const int C = heads * kWinHd;
+  const int i = wave * 32 + (lane & 31);
+  const bool row_ok = i < n;
+  const float scale2 = scale * kLog2e;
+  const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
+  float db[4][16];                                               // bias gradient of (row i, this lane's 64 keys), summed over the windows
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) db[t][r] = 0.f;
+
+  for (int w = blockIdx.x; w < windows; w += gridDim.x) {
+    const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * kWinHd;
+    win_load_tile(base, tok, n, qt);
+    win_load_tile(base + heads * kWinHd, tok, n, kt);
+    win_load_tile(base + 2 * heads * kWinHd, tok, n, vt);
+    win_load_tile(dout + static_cast<long>(w) * n * C + head * kWinHd, C, n, dt);
+    // D = rowsum(dout o out) of row i (this lane: 16 of the 32 channels), the row's log-sum-exp, its mask bits
+    float dpart = 0.f;
+    if (row_ok) {
+      const unsigned short* orow = out + (static_cast<long>(w) * n + i) * C + head * kWinHd;
+      const unsigned short* drow = dout + (static_cast<long>(w) * n + i) * C + head * kWinHd;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 o4 = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * kh);
+        const u32x4 d4 = *reinterpret_cast<const u32x4*>(drow + 16 * ks + 8 * kh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dpart += bf16_lo(o4[e]) * bf16_lo(d4[e]) + bf16_hi(o4[e]) * bf16_hi(d4[e]);
+      }
+    }
+    const float dsum = dpart + other_half(dpart);
+    const float lse_i = row_ok ? lse2[(static_cast<long>(w) * heads + head) * n + i] : INFINITY;
+    u32x4 mw{0u, 0u, 0u, 0u};
+    if (maskbits != nullptr && row_ok) mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
+    __syncthreads();
+
+    // ---- row side: P, dS of the wave's 32 rows; dq; P and scale dS -> LDS
+    const s16x8 qf0 = w32_rows(qt, lane, wave * 32, 0), qf1 = w32_rows(qt, lane, wave * 32, 1);
+    const s16x8 df0 = w32_rows(dt, lane, wave * 32, 0), df1 = w32_rows(dt, lane, wave * 32, 1);
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x16 sT, dpT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+      sT = mfma(w32_rows(kt, lane, 32 * t, 0), qf0, sT);
+      sT = mfma(w32_rows(kt, lane, 32 * t, 1), qf1, sT);
+      dpT = mfma(w32_rows(vt, lane, 32 * t, 0), df0, dpT);
+      dpT = mfma(w32_rows(vt, lane, 32 * t, 1), df1, dpT);
+      float s2[16];
+      win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2);
+      unsigned ppk[8], dpk[8];
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        float pr[2], dsr[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 2 * e2 + e;
+          pr[e] = fast_exp2(s2[r] - lse_i);                       // padding rows: lse = +inf -> 0; keys >= n: s2 = -inf -> 0
+          const float ds = pr[e] * (dpT[r] - dsum);
+          db[t][r] += ds;
+          dsr[e] = ds * scale;
+        }
+        ppk[e2] = pack_bf16(pr[0], pr[1]);
+        dpk[e2] = pack_bf16(dsr[0], dsr[1]);
+      }
+      // entries 4 qd .. 4 qd + 3 = keys 32 t + 8 qd + 4 kh .. + 3: 8 bytes of the row's P / dS line
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int off = i * kWinPPitch + 2 * (32 * t + 8 * qd + 4 * kh);
+        *reinterpret_cast<u32x2*>(pt + off) = u32x2{ppk[2 * qd], ppk[2 * qd + 1]};
+        *reinterpret_cast<u32x2*>(st + off) = u32x2{dpk[2 * qd], dpk[2 * qd + 1]};
+      }
+      s16x8 dsf[2];
+      packed_column_to_b_frags(dpk, dsf);
+      // dQ^T[channel][row] += K^T (scale dS)^T
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dq = mfma(w32_cols(kt, lane, 32 * t + 16 * j), dsf[j], dq);
+    }
+    if (row_ok) {
+      unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * kWinHd;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        *reinterpret_cast<u32x2*>(dst + 8 * qd + 4 * kh) =
+            u32x2{pack_bf16(dq[4 * qd], dq[4 * qd + 1]), pack_bf16(dq[4 * qd + 2], dq[4 * qd + 3])};
+    }
+    __syncthreads();
+
+    // ---- key side: the wave's 32 keys.  dV^T[channel][key] = dout^T P,  dK^T[channel][key] = q^T (scale dS)
+    f32x16 dv, dk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+#pragma unroll
+    for (int jr = 0; jr < 8; ++jr) {
+      dv = mfma(w32_cols(dt, lane, 16 * jr), wp_frag(pt, lane, 16 * jr, wave * 32), dv);
+      dk = mfma(w32_cols(qt, lane, 16 * jr), wp_frag(st, lane, 16 * jr, wave * 32), dk);
+    }
+    if (row_ok) {                                                   // here i is the lane's KEY
+      unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * kWinHd;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        *reinterpret_cast<u32x2*>(dst + heads * kWinHd + 8 * qd + 4 * kh) =
+            u32x2{pack_bf16(dk[4 * qd], dk[4 * qd + 1]), pack_bf16(dk[4 * qd + 2], dk[4 * qd + 3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * heads * kWinHd + 8 * qd + 4 * kh) =
+            u32x2{pack_bf16(dv[4 * qd], dv[4 * qd + 1]), pack_bf16(dv[4 * qd + 2], dv[4 * qd + 3])};
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the bias gradient of this workgroup's windows: one atomic per (row, key)
+  if (row_ok) {
+    float* drow = dbias + (static_cast<long>(head) * n + i) * kWinN;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (key < n) atomicAdd(drow + key, db[t][r]);
+      }
+  }
+}
+
 }  // namespace transoar
 
 using namespace transoar;
@@ -708,4 +1002,26 @@ extern "C" int transoar_roi_attn_backward(const void* q, const void* k, const vo
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_attn_abi_version(void) { return 1; }
+extern "C" int transoar_win_attn_forward(const void* qkv, const float* bias, const unsigned* maskbits, void* out, float* lse2, int windows,
+                                         int n_win, int n, int heads, int head_dim, float scale, void* hip_stream) {
+  if (!qkv || !bias || !out || !lse2) return TRANSOAR_ATTN_ERR_NULL;
+  if (head_dim != kWinHd || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  hipLaunchKernelGGL(win_attn_fwd, dim3(windows, heads), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<const unsigned short*>(qkv), bias, maskbits, static_cast<unsigned short*>(out), lse2, n, heads, n_win, scale);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_win_attn_backward(const void* qkv, const void* out, const void* dout, const float* lse2, const float* bias,
+                                          const unsigned* maskbits, void* dqkv, float* dbias, int windows, int n_win, int n, int heads,
+                                          int head_dim, float scale, void* hip_stream) {
+  if (!qkv || !out || !dout || !lse2 || !bias || !dqkv || !dbias) return TRANSOAR_ATTN_ERR_NULL;
+  if (head_dim != kWinHd || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  // one resident set of workgroups (112 KiB of LDS: one per CU), the windows of a head dealt round-robin
+  const int per_head = std::max(1, std::min(windows, 256 / std::min(heads, 256)));
+  hipLaunchKernelGGL(win_attn_bwd, dim3(per_head, heads), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<const unsigned short*>(qkv), static_cast<const unsigned short*>(out), static_cast<const unsigned short*>(dout),
+                     lse2, bias, maskbits, static_cast<unsigned short*>(dqkv), dbias, n, heads, n_win, windows, scale);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_attn_abi_version(void) { return 2; }

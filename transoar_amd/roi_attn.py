@@ -17,7 +17,7 @@ import torch
 from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtransoar_attn.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 CHANNELS = 384
 MAX_ROWS = 512
 

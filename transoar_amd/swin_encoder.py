@@ -25,6 +25,42 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import rows, win_attn
+from .token_linear import token_linear
+
+MIN_TOKENS = 8192            # token matrices at least this tall take the hand-written GEMMs (token_linear)
+
+
+def _fast(x):
+    """The hand-written path of a Swin block: bf16 autocast on the GPU (fp32 / CPU: the plain torch formulation, which the
+    golden parity tests pin)."""
+    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+
+
+class _Rows(torch.autograd.Function):
+    """x (B, S, C)[:, index] with the row kernels of include/transoar_rows.h both ways: forward a row gather, backward
+    a pull over the CSR inverse of the index list (no atomics, no index_put: torch's indexing backward of the window
+    partition took 21 ms per step in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, index, inv_ptr, inv_idx):
+        ctx.n_rows = x.shape[1]
+        ctx.save_for_backward(inv_ptr, inv_idx)
+        return rows.gather(x, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv_ptr, inv_idx = ctx.saved_tensors
+        return rows.pull_sum(g.contiguous(), inv_ptr, inv_idx, ctx.n_rows), None, None, None
+
+
+def _csr_inverse(index, n_rows):
+    """index (K,) long -> (ptr (n_rows + 1,), idx (K,)) int32: the list slots that hold each source row."""
+    order = torch.argsort(index, stable=True)
+    counts = torch.bincount(index, minlength=n_rows)
+    ptr = torch.cat((counts.new_zeros(1), counts.cumsum(0)))
+    return ptr.int(), order.int()
+
 
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm.models.layers.DropPath as the reference uses it): in training a
@@ -73,7 +109,12 @@ class _WindowLayout:
         inv = torch.empty(n_tok + 1, dtype=torch.long)
         inv[src] = torch.arange(src.numel())
         self.scatter = inv[:n_tok].to(device)
+        # the same two lists for the row kernels: int32, with the CSR inverse each backward pulls over
+        self.gather32, self.scatter32 = self.gather.int(), self.scatter.int()
+        self.gather_inv = tuple(t.to(device) for t in _csr_inverse(src, n_tok + 1))
+        self.scatter_inv = tuple(t.to(device) for t in _csr_inverse(inv[:n_tok], src.numel()))
         self.mask = None
+        self.mask_bits = None
         if any(s > 0 for s in shift):
             # region label of every padded position (3 slabs per axis), as seen after the roll
             # (encoder_blocks.py:373-386): tokens of one window attend only within equal labels
@@ -84,6 +125,8 @@ class _WindowLayout:
             lab = label.view(nd, win[0], nh, win[1], nw, win[2]).permute(0, 2, 4, 1, 3, 5).reshape(self.n_windows, self.n_per)
             diff = lab[:, None, :] != lab[:, :, None]
             self.mask = torch.zeros(diff.shape).masked_fill_(diff, -100.0).to(device)
+            if self.n_per <= win_attn.MAX_TOKENS:
+                self.mask_bits = win_attn.mask_bits(self.mask)
 
 
 _LAYOUTS = {}
@@ -120,10 +163,17 @@ class WindowAttention3D(nn.Module):
         idx = self.relative_position_index[:n, :n].reshape(-1)
         return self.relative_position_bias_table[idx].view(n, n, -1).permute(2, 0, 1)
 
-    def forward(self, x, mask=None):
-        """x (B, nW, n, C) tokens per window; mask (nW, n, n) additive or None."""
+    def forward(self, x, mask=None, mask_bits=None):
+        """x (B, nW, n, C) tokens per window; mask (nW, n, n) additive or None (mask_bits: the same as one bit per pair)."""
         b, nw, n, c = x.shape
         h = self.num_heads
+        if (_fast(x) and x.dtype == torch.bfloat16 and c == h * win_attn.HEAD_DIM and n <= win_attn.MAX_TOKENS
+                and (mask is None or mask_bits is not None) and not (self.training and self.attn_drop.p > 0)
+                and win_attn.ENABLED):
+            # qkv projection -> ONE window-attention kernel over its output as it lies in memory -> output projection
+            qkv = token_linear(x, self.qkv.weight, self.qkv.bias, force_hip=True, min_tokens=MIN_TOKENS)
+            out = win_attn.window_attention(qkv.contiguous(), self.position_bias(n), mask_bits, h, self.scale)
+            return self.proj_drop(token_linear(out, self.proj.weight, self.proj.bias, force_hip=True, min_tokens=MIN_TOKENS))
         q, k, v = self.qkv(x).view(b, nw, n, 3, h, c // h).permute(3, 0, 1, 4, 2, 5)      # each (B, nW, h, n, hd)
         bias = self.position_bias(n).to(q.dtype)[None]                                    # (1, h, n, n)
         if mask is not None:
@@ -142,6 +192,9 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if _fast(x):
+            hid = self.act(token_linear(x, self.fc1.weight, self.fc1.bias, force_hip=True, min_tokens=MIN_TOKENS))
+            return self.drop(token_linear(self.drop(hid), self.fc2.weight, self.fc2.bias, force_hip=True, min_tokens=MIN_TOKENS))
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -163,6 +216,14 @@ class SwinBlock(nn.Module):
         win, shift = effective_window(grid, self.window_size, self.shift_size)
         lay = window_layout(grid, win, shift, x.device)
         y = self.norm1(x)
+        if _fast(x) and (c * 2) % 16 == 0:
+            # bf16 tokens (what the qkv projection rounds them to anyway) through the row kernels both ways
+            y = torch.cat((y.to(torch.bfloat16), y.new_zeros((b, 1, c), dtype=torch.bfloat16)), dim=1)     # row n_tok: the padding token
+            y = _Rows.apply(y, lay.gather32, *lay.gather_inv).view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
+            y = self.attn(y, lay.mask, lay.mask_bits)
+            y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, *lay.scatter_inv)                # merge + shift back + crop
+            x = x + self.drop_path(y)
+            return x + self.drop_path(self.mlp(self.norm2(x).to(torch.bfloat16)))
         y = torch.cat((y, y.new_zeros(b, 1, c)), dim=1)                      # row n_tok: the padding token
         y = y[:, lay.gather].view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
         y = self.attn(y, lay.mask)
