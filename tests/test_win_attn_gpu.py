@@ -27,12 +27,13 @@ def _rel(a, b):
     return float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-30)
 
 
+@pytest.mark.parametrize("head_dim", [16, 32])
 @pytest.mark.parametrize("case", [(2, 8, 125, 3, True), (1, 3, 40, 6, False), (2, 2, 125, 24, True), (1, 5, 100, 3, True),
                                   (3, 300, 125, 3, True)])
-def test_window_attention_kernels_match_the_explicit_formulation(case):
+def test_window_attention_kernels_match_the_explicit_formulation(case, head_dim):
     from transoar_amd import win_attn
     b, nw, n, heads, shifted = case
-    c = heads * 32
+    c = heads * head_dim
     g = torch.Generator().manual_seed(n + heads)
     qkv = torch.randn(b, nw, n, 3 * c, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
     bias = (0.5 * torch.randn(heads, n, n, generator=g)).cuda().requires_grad_(True)
@@ -41,7 +42,7 @@ def test_window_attention_kernels_match_the_explicit_formulation(case):
         label = torch.randint(0, 3, (nw, n), generator=g)
         mask = torch.zeros(nw, n, n).masked_fill_(label[:, None, :] != label[:, :, None], -100.0).cuda()
         bits = win_attn.mask_bits(mask)
-    scale = 32 ** -0.5
+    scale = head_dim ** -0.5
     assert win_attn.usable(qkv, heads)
     out = win_attn.window_attention(qkv, bias, bits, heads, scale)
     dout = torch.randn(out.shape, generator=g).to(torch.bfloat16).cuda()

@@ -1,0 +1,10 @@
+set -x
+mkdir -p gpurun_out/r04d
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_win_attn_gpu.py tests/test_roi_attn_gpu.py tests/test_rows_gpu.py "tests/test_model_parity.py::test_g9_full_width_swin_stage_on_the_kernels" tests/test_swin_gpu.py -m gpu -x -q > gpurun_out/r04d/tests.log 2>&1; echo "rc=$?" >> gpurun_out/r04d/tests.log
+grep -n "passed\|failed\|^E " gpurun_out/r04d/tests.log | head -20
+timeout 300 python tools/bench_roi_attn.py > gpurun_out/r04d/roi_attn_bench.jsonl 2>&1; cat gpurun_out/r04d/roi_attn_bench.jsonl
+timeout 900 python bench.py --swin --no-refine --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r04d/bench_swin.json 2> gpurun_out/r04d/bench_swin.err; head -c 400 gpurun_out/r04d/bench_swin.json; echo; tail -3 gpurun_out/r04d/bench_swin.err | cut -c1-300
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d /root/repo/gpurun_out/r04d/prof_swin -o p -- python /root/repo/bench.py --swin --no-refine --no-graph --no-cpu-baseline --steps 4 --warmup 2 > /root/repo/gpurun_out/r04d/prof_swin.log 2>&1
+cd /root/repo; find gpurun_out/r04d/prof_swin -name '*kernel_trace.csv' -delete
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04d/bench_default.json 2> gpurun_out/r04d/bench_default.err; head -c 400 gpurun_out/r04d/bench_default.json

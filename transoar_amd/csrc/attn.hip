@@ -260,12 +260,31 @@ TRANSOAR_ATTN_KERNEL void roi_attn_fwd(
       dma_tile(krs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx, wave, lane);
       dma_tile(vrs, g_byte + static_cast<unsigned>(t + 1) * kTile, nx + kTile, wave, lane);
     }
-    // ---- S^T[key][row] = K Q^T
+    // ---- S^T[key][row] = K Q^T.  Two accumulators (a chain of MFMAs on ONE accumulator issues every 64 cycles, not 32)
+    // and the K fragments fetched six K steps ahead of their use (one wave per SIMD: nobody else hides the LDS latency)
     f32x16 sT;
+    {
+      f32x16 s0, s1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sT[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      s16x8 fk[2][6];
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) sT = mfma(frag_rows<0>(lds, fs, ks), qf[ks], sT);
+      for (int e = 0; e < 6; ++e) fk[0][e] = frag_rows<0>(lds, fs, e);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        if (gq + 1 < 4) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) fk[(gq + 1) & 1][e] = frag_rows<0>(lds, fs, 6 * (gq + 1) + e);
+        }
+#pragma unroll
+        for (int e = 0; e < 6; e += 2) {
+          s0 = mfma(fk[gq & 1][e], qf[6 * gq + e], s0);
+          s1 = mfma(fk[gq & 1][e + 1], qf[6 * gq + e + 1], s1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[r] = s0[r] + s1[r];
+    }
     // ---- mask, online softmax (log2 units)
     const unsigned bits = bits_o[t] >> (4 * kh);            // this lane's keys: (r & 3) + 8 (r >> 2) + 4 kh
     float s2[16];
@@ -306,9 +325,9 @@ TRANSOAR_ATTN_KERNEL void roi_attn_fwd(
     column_to_b_frags(p, pf);
     // ---- O^T[channel][row] += V^T P^T
 #pragma unroll
-    for (int ct = 0; ct < kCT; ++ct)
+    for (int j = 0; j < 2; ++j)                     // j outermost: consecutive MFMAs write different accumulators
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[ct] = mfma(frag_cols<kTile>(lds, fs, j, ct), pf[j], acc[ct]);
+      for (int ct = 0; ct < kCT; ++ct) acc[ct] = mfma(frag_cols<kTile>(lds, fs, j, ct), pf[j], acc[ct]);
     frag_shift(fs, st ? -2 * kTile : 2 * kTile);
     dma_wait();
     __syncthreads();
@@ -442,9 +461,10 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_q(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) sT = mfma(frag_rows<0>(lds, fs, ks), qf[ks], sT);
-#pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) dpT = mfma(frag_rows<kTile>(lds, fs, ks), df[ks], dpT);
+    for (int ks = 0; ks < kKS; ++ks) {              // the two chains interleaved: consecutive MFMAs on different accumulators
+      sT = mfma(frag_rows<0>(lds, fs, ks), qf[ks], sT);
+      dpT = mfma(frag_rows<kTile>(lds, fs, ks), df[ks], dpT);
+    }
     const unsigned bits = bits_o[t] >> (4 * kh);
     unsigned dpk[8];
 #pragma unroll
@@ -463,9 +483,9 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_q(
     packed_column_to_b_frags(dpk, dsf);
     // dQ^T[channel][row] += K^T dS^T
 #pragma unroll
-    for (int ct = 0; ct < kCT; ++ct)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[ct] = mfma(frag_cols<0>(lds, fs, j, ct), dsf[j], acc[ct]);
+      for (int ct = 0; ct < kCT; ++ct) acc[ct] = mfma(frag_cols<0>(lds, fs, j, ct), dsf[j], acc[ct]);
     frag_shift(fs, st ? -2 * kTile : 2 * kTile);
     dma_wait();
     __syncthreads();
@@ -577,6 +597,7 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    // (interleaving the two chains, as the dq kernel does, costs this kernel 39 spilled registers: it is at 512)
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) s = mfma(frag_rows<0>(lds, fs, ks), kf[ks], s);
 #pragma unroll
@@ -601,6 +622,8 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
     packed_column_to_b_frags(ppk, pf);
     packed_column_to_b_frags(dpk, dsf);
     // dTok^T[channel][key] += Q^T dS + dctx^T P
+    // (ct outermost: with j outermost -- consecutive MFMAs on different accumulators, as in the other two kernels --
+    // hipcc keeps 39 more registers alive than this kernel has)
 #pragma unroll
     for (int ct = 0; ct < kCT; ++ct)
 #pragma unroll
@@ -637,7 +660,7 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
 //     S = scale q k^T + relative-position bias[head] + shifted-window mask[window]      (n <= 128 tokens, head dim 32)
 //     out = softmax(S) v
 // Round 3 ran this on torch SDPA with a dense additive mask (the fp32 math path: six fp32 batched GEMMs, softmax,
-// isneginf / where / reduce passes over (windows, heads, n, n) tensors).  Here one workgroup owns a (window, head):
+// isneginf / where / reduce passes over (windows, heads, n, n) tensors).  Head dimension 16 or 32.  Here one workgroup owns a (window, head):
 // K and V (128 x 32) sit in LDS, a wave owns 32 query rows and holds all their 128 scores in registers (exact
 // softmax, no running maximum), bias rows are read as aligned float4 (the host pads the key axis to 128), the mask is
 // one bit per (row, key) ("region labels differ").  The backward kernel is persistent over the windows of a head so
@@ -645,25 +668,55 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
 // Tiles [rows][32 channels] keep their four 16-byte pieces at piece ^ ((row >> 2) & 3): conflict-free for the
 // ds_read_b128 operand fragments, and a transposing read's four rows still tile the 64 banks.
 // ===========================================================================
-constexpr int kWinHd = 32;                 // head dimension
 constexpr int kWinN = 128;                 // tokens of a window, padded
-constexpr int kWinTile = kWinN * kWinHd * 2;      // 8 KiB
 constexpr int kWinPPitch = 320;            // bytes per row of the P / dS tiles (256 + 64: four rows of a transposing read tile the banks)
 
-__device__ __forceinline__ int w32_off(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
-// rows [r0, r0 + 32) of a [rows][32] tile as an MFMA operand [32 rows][16 channels of K step ks]
-__device__ __forceinline__ s16x8 w32_rows(const unsigned char* tile, int lane, int r0, int ks) {
-  return *reinterpret_cast<const s16x8*>(tile + w32_off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
-}
-// the transposed tile as an MFMA operand [32 channels][16 rows R0 + 8 kh .. + 7]
-__device__ __forceinline__ s16x8 w32_cols(const unsigned char* tile, int lane, int R0) {
-  const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
-  const int n0 = R0 + 8 * kh + r, n1 = n0 + 4;
-  const int p = 2 * g + (c >> 1);
-  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + w32_off(n0, p) + 8 * (c & 1)));
-  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + w32_off(n1, p) + 8 * (c & 1)));
-  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
+// Tiles [128 rows][HD channels] bf16, HD = 16 or 32 (the shipped configurations have 16: 48 / 96 / 192 / 384 channels
+// with 3 / 6 / 12 / 24 heads, config/attn_fpn_*: encoder stage k works at the width of stage k - 1's output).  A row's
+// 16-byte pieces are XORed with row bits so that the 16 rows of a ds_read_b128 lane group hit 16 different 4-bank slots.
+template <int HD> struct WinTile {
+  static constexpr int kRow = HD * 2;                  // bytes per row: 32 or 64
+  static constexpr int kPieces = HD / 8;               // 2 or 4
+  static constexpr int kBytes = kWinN * kRow;
+  static __device__ __forceinline__ int off(int row, int piece) {
+    const int key = HD == 32 ? (row >> 2) & 3 : (row >> 3) & 1;
+    return row * kRow + ((piece ^ key) << 4);
+  }
+  // rows [r0, r0 + 32) as an MFMA operand [32 rows][16 channels of K step ks] (HD = 16: ks = 0 only)
+  static __device__ __forceinline__ s16x8 rows(const unsigned char* tile, int lane, int r0, int ks) {
+    return *reinterpret_cast<const s16x8*>(tile + off(r0 + (lane & 31), 2 * ks + (lane >> 5)));
+  }
+  // the transposed tile as an MFMA operand [32 channels][16 rows R0 + 8 kh .. + 7]; HD = 16: channels 16..31 are zero
+  static __device__ __forceinline__ s16x8 cols(const unsigned char* tile, int lane, int R0) {
+    const int kh = lane >> 5, r = (lane & 15) >> 2, g = HD == 32 ? (lane >> 4) & 1 : 0, c = lane & 3;
+    const int n0 = R0 + 8 * kh + r, n1 = n0 + 4;
+    const int p = 2 * g + (c >> 1);
+    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off(n0, p) + 8 * (c & 1)));
+    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off(n1, p) + 8 * (c & 1)));
+    s16x8 f = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if (HD == 16 && ((lane >> 4) & 1)) f = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    return f;
+  }
+  // one (window, head) slice [n tokens][HD] of a token matrix (tokens `tok_elems` elements apart) -> LDS tile;
+  // rows >= n are zero.  256 threads: thread = (row, half of the row)
+  static __device__ __forceinline__ void load(const unsigned short* __restrict__ src, long tok_elems, int n, unsigned char* tile) {
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    if constexpr (HD == 32) {
+      u32x4 a{0u, 0u, 0u, 0u}, b{0u, 0u, 0u, 0u};
+      if (row < n) {
+        const u32x4* g = reinterpret_cast<const u32x4*>(src + row * tok_elems + 16 * half);
+        a = g[0];
+        b = g[1];
+      }
+      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half)) = a;
+      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half + 1)) = b;
+    } else {
+      u32x4 a{0u, 0u, 0u, 0u};
+      if (row < n) a = *reinterpret_cast<const u32x4*>(src + row * tok_elems + 8 * half);
+      *reinterpret_cast<u32x4*>(tile + off(row, half)) = a;
+    }
+  }
+};
 // a [row][key] tile (pitch kWinPPitch) as the MFMA B operand [k = rows R0 + 8 kh .. + 7][n = key K0 + (lane & 31)]
 __device__ __forceinline__ s16x8 wp_frag(const unsigned char* tile, int lane, int R0, int K0) {
   const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
@@ -671,19 +724,6 @@ __device__ __forceinline__ s16x8 wp_frag(const unsigned char* tile, int lane, in
   const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
   const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * kWinPPitch));
   return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// one (window, head) slice [n tokens][32 channels] of the qkv tensor (tokens `tok_elems` elements apart) -> LDS tile;
-// rows >= n are zero.  256 threads: thread = (row, half of the row).
-__device__ __forceinline__ void win_load_tile(const unsigned short* __restrict__ src, long tok_elems, int n, unsigned char* tile) {
-  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-  u32x4 a{0u, 0u, 0u, 0u}, b{0u, 0u, 0u, 0u};
-  if (row < n) {
-    const u32x4* g = reinterpret_cast<const u32x4*>(src + row * tok_elems + 16 * half);
-    a = g[0];
-    b = g[1];
-  }
-  *reinterpret_cast<u32x4*>(tile + w32_off(row, 2 * half)) = a;
-  *reinterpret_cast<u32x4*>(tile + w32_off(row, 2 * half + 1)) = b;
 }
 
 // scores of the wave's 32 rows against key tile t, in log2 units, masked: lane = (row i, half kh), entry r = key
@@ -705,26 +745,36 @@ __device__ __forceinline__ void win_scores(const f32x16& sT, int t, int kh, int 
     }
   }
 }
+// the wave's 32 x HD result (channel (r & 3) + 8 (r >> 2) + 4 kh of row / key `lane & 31`) -> 8-byte pieces of a token row
+template <int HD>
+__device__ __forceinline__ void win_store(unsigned short* __restrict__ dst, const f32x16& acc, int kh) {
+#pragma unroll
+  for (int qd = 0; qd < HD / 8; ++qd)
+    *reinterpret_cast<u32x2*>(dst + 8 * qd + 4 * kh) =
+        u32x2{pack_bf16(acc[4 * qd], acc[4 * qd + 1]), pack_bf16(acc[4 * qd + 2], acc[4 * qd + 3])};
+}
 
 // forward: grid (windows, heads)
+template <int HD>
 __global__ __launch_bounds__(256) void win_attn_fwd(
     const unsigned short* __restrict__ qkv, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
     unsigned short* __restrict__ out, float* __restrict__ lse2, int n, int heads, int n_win, float scale) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kWinTile];
+  using T = WinTile<HD>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * T::kBytes];
   unsigned char* kt = lds;
-  unsigned char* vt = lds + kWinTile;
+  unsigned char* vt = lds + T::kBytes;
   const int w = blockIdx.x, head = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
-  const long tok = 3L * heads * kWinHd;                                   // elements per token of qkv
-  const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * kWinHd;
-  win_load_tile(base + heads * kWinHd, tok, n, kt);
-  win_load_tile(base + 2 * heads * kWinHd, tok, n, vt);
+  const long tok = 3L * heads * HD;                                       // elements per token of qkv
+  const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
+  T::load(base + heads * HD, tok, n, kt);
+  T::load(base + 2 * heads * HD, tok, n, vt);
   const int i = wave * 32 + (lane & 31);
   const bool row_ok = i < n;
-  s16x8 qf[2];
+  s16x8 qf[HD / 16];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < HD / 16; ++ks) {
     u32x4 x{0u, 0u, 0u, 0u};
     if (row_ok) x = *reinterpret_cast<const u32x4*>(base + i * tok + 16 * ks + 8 * kh);
     qf[ks] = __builtin_bit_cast(s16x8, x);
@@ -744,7 +794,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd(
 #pragma unroll
     for (int r = 0; r < 16; ++r) sT[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) sT = mfma(w32_rows(kt, lane, 32 * t, ks), qf[ks], sT);
+    for (int ks = 0; ks < HD / 16; ++ks) sT = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT);
     win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) m = fmaxf(m, s2[t][r]);
@@ -771,35 +821,33 @@ __global__ __launch_bounds__(256) void win_attn_fwd(
     s16x8 pf[2];
     column_to_b_frags(p, pf);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc = mfma(w32_cols(vt, lane, 32 * t + 16 * j), pf[j], acc);
+    for (int j = 0; j < 2; ++j) acc = mfma(T::cols(vt, lane, 32 * t + 16 * j), pf[j], acc);
   }
   if (row_ok) {
-    unsigned short* dst = out + (static_cast<long>(w) * n + i) * (heads * kWinHd) + head * kWinHd;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      *reinterpret_cast<u32x2*>(dst + 8 * qd + 4 * kh) =
-          u32x2{pack_bf16(acc[4 * qd], acc[4 * qd + 1]), pack_bf16(acc[4 * qd + 2], acc[4 * qd + 3])};
+    win_store<HD>(out + (static_cast<long>(w) * n + i) * (heads * HD) + head * HD, acc, kh);
     if (kh == 0) lse2[(static_cast<long>(w) * heads + head) * n + i] = m + log2f(l);
   }
 }
 
 // backward: grid (persistent workgroups, heads); workgroup x walks the windows x, x + gridDim.x, ... of its head
+template <int HD>
 __global__ __launch_bounds__(256) void win_attn_bwd(
     const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ out, const unsigned short* __restrict__ dout,
     const float* __restrict__ lse2, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
     unsigned short* __restrict__ dqkv, float* __restrict__ dbias, int n, int heads, int n_win, int windows, float scale) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWinTile + 2 * kWinN * kWinPPitch];
+  using T = WinTile<HD>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * T::kBytes + 2 * kWinN * kWinPPitch];
   unsigned char* kt = lds;
-  unsigned char* vt = lds + kWinTile;
-  unsigned char* qt = lds + 2 * kWinTile;
-  unsigned char* dt = lds + 3 * kWinTile;
-  unsigned char* pt = lds + 4 * kWinTile;                       // P   [row][key] bf16
+  unsigned char* vt = lds + T::kBytes;
+  unsigned char* qt = lds + 2 * T::kBytes;
+  unsigned char* dt = lds + 3 * T::kBytes;
+  unsigned char* pt = lds + 4 * T::kBytes;                      // P   [row][key] bf16
   unsigned char* st = pt + kWinN * kWinPPitch;                  // scale * dS [row][key] bf16
   const int head = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
-  const long tok = 3L * heads * kWinHd;
-  const int C = heads * kWinHd;
+  const long tok = 3L * heads * HD;
+  const int C = heads * HD;
   const int i = wave * 32 + (lane & 31);
   const bool row_ok = i < n;
   const float scale2 = scale * kLog2e;
@@ -811,18 +859,18 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
     for (int r = 0; r < 16; ++r) db[t][r] = 0.f;
 
   for (int w = blockIdx.x; w < windows; w += gridDim.x) {
-    const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * kWinHd;
-    win_load_tile(base, tok, n, qt);
-    win_load_tile(base + heads * kWinHd, tok, n, kt);
-    win_load_tile(base + 2 * heads * kWinHd, tok, n, vt);
-    win_load_tile(dout + static_cast<long>(w) * n * C + head * kWinHd, C, n, dt);
-    // D = rowsum(dout o out) of row i (this lane: 16 of the 32 channels), the row's log-sum-exp, its mask bits
+    const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
+    T::load(base, tok, n, qt);
+    T::load(base + heads * HD, tok, n, kt);
+    T::load(base + 2 * heads * HD, tok, n, vt);
+    T::load(dout + static_cast<long>(w) * n * C + head * HD, C, n, dt);
+    // D = rowsum(dout o out) of row i (this lane: half of the head's channels), the row's log-sum-exp, its mask bits
     float dpart = 0.f;
     if (row_ok) {
-      const unsigned short* orow = out + (static_cast<long>(w) * n + i) * C + head * kWinHd;
-      const unsigned short* drow = dout + (static_cast<long>(w) * n + i) * C + head * kWinHd;
+      const unsigned short* orow = out + (static_cast<long>(w) * n + i) * C + head * HD;
+      const unsigned short* drow = dout + (static_cast<long>(w) * n + i) * C + head * HD;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < HD / 16; ++ks) {
         const u32x4 o4 = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * kh);
         const u32x4 d4 = *reinterpret_cast<const u32x4*>(drow + 16 * ks + 8 * kh);
 #pragma unroll
@@ -836,8 +884,12 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
     __syncthreads();
 
     // ---- row side: P, dS of the wave's 32 rows; dq; P and scale dS -> LDS
-    const s16x8 qf0 = w32_rows(qt, lane, wave * 32, 0), qf1 = w32_rows(qt, lane, wave * 32, 1);
-    const s16x8 df0 = w32_rows(dt, lane, wave * 32, 0), df1 = w32_rows(dt, lane, wave * 32, 1);
+    s16x8 qf[HD / 16], df[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      qf[ks] = T::rows(qt, lane, wave * 32, ks);
+      df[ks] = T::rows(dt, lane, wave * 32, ks);
+    }
     f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -846,10 +898,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
       f32x16 sT, dpT;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
-      sT = mfma(w32_rows(kt, lane, 32 * t, 0), qf0, sT);
-      sT = mfma(w32_rows(kt, lane, 32 * t, 1), qf1, sT);
-      dpT = mfma(w32_rows(vt, lane, 32 * t, 0), df0, dpT);
-      dpT = mfma(w32_rows(vt, lane, 32 * t, 1), df1, dpT);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        sT = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT);
+        dpT = mfma(T::rows(vt, lane, 32 * t, ks), df[ks], dpT);
+      }
       float s2[16];
       win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2);
       unsigned ppk[8], dpk[8];
@@ -878,15 +931,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
       packed_column_to_b_frags(dpk, dsf);
       // dQ^T[channel][row] += K^T (scale dS)^T
 #pragma unroll
-      for (int j = 0; j < 2; ++j) dq = mfma(w32_cols(kt, lane, 32 * t + 16 * j), dsf[j], dq);
+      for (int j = 0; j < 2; ++j) dq = mfma(T::cols(kt, lane, 32 * t + 16 * j), dsf[j], dq);
     }
-    if (row_ok) {
-      unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * kWinHd;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd)
-        *reinterpret_cast<u32x2*>(dst + 8 * qd + 4 * kh) =
-            u32x2{pack_bf16(dq[4 * qd], dq[4 * qd + 1]), pack_bf16(dq[4 * qd + 2], dq[4 * qd + 3])};
-    }
+    if (row_ok) win_store<HD>(dqkv + (static_cast<long>(w) * n + i) * tok + head * HD, dq, kh);
     __syncthreads();
 
     // ---- key side: the wave's 32 keys.  dV^T[channel][key] = dout^T P,  dK^T[channel][key] = q^T (scale dS)
@@ -895,18 +942,13 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
     for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
 #pragma unroll
     for (int jr = 0; jr < 8; ++jr) {
-      dv = mfma(w32_cols(dt, lane, 16 * jr), wp_frag(pt, lane, 16 * jr, wave * 32), dv);
-      dk = mfma(w32_cols(qt, lane, 16 * jr), wp_frag(st, lane, 16 * jr, wave * 32), dk);
+      dv = mfma(T::cols(dt, lane, 16 * jr), wp_frag(pt, lane, 16 * jr, wave * 32), dv);
+      dk = mfma(T::cols(qt, lane, 16 * jr), wp_frag(st, lane, 16 * jr, wave * 32), dk);
     }
     if (row_ok) {                                                   // here i is the lane's KEY
-      unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * kWinHd;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        *reinterpret_cast<u32x2*>(dst + heads * kWinHd + 8 * qd + 4 * kh) =
-            u32x2{pack_bf16(dk[4 * qd], dk[4 * qd + 1]), pack_bf16(dk[4 * qd + 2], dk[4 * qd + 3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * heads * kWinHd + 8 * qd + 4 * kh) =
-            u32x2{pack_bf16(dv[4 * qd], dv[4 * qd + 1]), pack_bf16(dv[4 * qd + 2], dv[4 * qd + 3])};
-      }
+      unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * HD;
+      win_store<HD>(dst + heads * HD, dk, kh);
+      win_store<HD>(dst + 2 * heads * HD, dv, kh);
     }
     __syncthreads();
   }
@@ -1005,9 +1047,12 @@ extern "C" int transoar_roi_attn_backward(const void* q, const void* k, const vo
 extern "C" int transoar_win_attn_forward(const void* qkv, const float* bias, const unsigned* maskbits, void* out, float* lse2, int windows,
                                          int n_win, int n, int heads, int head_dim, float scale, void* hip_stream) {
   if (!qkv || !bias || !out || !lse2) return TRANSOAR_ATTN_ERR_NULL;
-  if (head_dim != kWinHd || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
-  hipLaunchKernelGGL(win_attn_fwd, dim3(windows, heads), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                     static_cast<const unsigned short*>(qkv), bias, maskbits, static_cast<unsigned short*>(out), lse2, n, heads, n_win, scale);
+  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  auto qs = static_cast<const unsigned short*>(qkv);
+  auto os = static_cast<unsigned short*>(out);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (head_dim == 32) hipLaunchKernelGGL(win_attn_fwd<32>, dim3(windows, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, scale);
+  else hipLaunchKernelGGL(win_attn_fwd<16>, dim3(windows, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, scale);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -1015,12 +1060,16 @@ extern "C" int transoar_win_attn_backward(const void* qkv, const void* out, cons
                                           const unsigned* maskbits, void* dqkv, float* dbias, int windows, int n_win, int n, int heads,
                                           int head_dim, float scale, void* hip_stream) {
   if (!qkv || !out || !dout || !lse2 || !bias || !dqkv || !dbias) return TRANSOAR_ATTN_ERR_NULL;
-  if (head_dim != kWinHd || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
-  // one resident set of workgroups (112 KiB of LDS: one per CU), the windows of a head dealt round-robin
+  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  // one resident set of workgroups (~100 KiB of LDS: one per CU), the windows of a head dealt round-robin
   const int per_head = std::max(1, std::min(windows, 256 / std::min(heads, 256)));
-  hipLaunchKernelGGL(win_attn_bwd, dim3(per_head, heads), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                     static_cast<const unsigned short*>(qkv), static_cast<const unsigned short*>(out), static_cast<const unsigned short*>(dout),
-                     lse2, bias, maskbits, static_cast<unsigned short*>(dqkv), dbias, n, heads, n_win, windows, scale);
+  auto qs = static_cast<const unsigned short*>(qkv);
+  auto os = static_cast<const unsigned short*>(out);
+  auto ds = static_cast<const unsigned short*>(dout);
+  auto dq = static_cast<unsigned short*>(dqkv);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (head_dim == 32) hipLaunchKernelGGL(win_attn_bwd<32>, dim3(per_head, heads), dim3(256), 0, st, qs, os, ds, lse2, bias, maskbits, dq, dbias, n, heads, n_win, windows, scale);
+  else hipLaunchKernelGGL(win_attn_bwd<16>, dim3(per_head, heads), dim3(256), 0, st, qs, os, ds, lse2, bias, maskbits, dq, dbias, n, heads, n_win, windows, scale);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void rows_gather(const u32x4r* __restrict__ sr
   const int v = static_cast<int>(t - k * vec_per_row);
   if (k >= K) return;
   const long b = blockIdx.y;
-  out[(b * K + k) * vec_per_row + v] = src[(b * S + index[k]) * vec_per_row + v];
+  const int s = index[k];                       // negative: a zero row (the padding slots of the Swin window layout)
+  out[(b * K + k) * vec_per_row + v] = s < 0 ? u32x4r{0u, 0u, 0u, 0u} : src[(b * S + s) * vec_per_row + v];
 }
 
 template <bool BF16>

@@ -38,28 +38,21 @@ def _fast(x):
 
 
 class _Rows(torch.autograd.Function):
-    """x (B, S, C)[:, index] with the row kernels of include/transoar_rows.h both ways: forward a row gather, backward
-    a pull over the CSR inverse of the index list (no atomics, no index_put: torch's indexing backward of the window
-    partition took 21 ms per step in fp32)."""
+    """x (B, S, C)[:, index] with the row-gather kernel of include/transoar_rows.h BOTH ways.  The window partition is a
+    permutation of the tokens plus a few padding slots, so the adjoint of a gather is again a gather: through the inverse
+    list, with -1 (= a zero row) where a source row is referenced by no slot.  (torch's indexing backward of the window
+    partition took 21 ms per step in fp32; a pull over the CSR inverse, as the Focused Decoder's many-to-one key lists
+    need, 15 ms on these 96-byte rows.)"""
 
     @staticmethod
-    def forward(ctx, x, index, inv_ptr, inv_idx):
-        ctx.n_rows = x.shape[1]
-        ctx.save_for_backward(inv_ptr, inv_idx)
+    def forward(ctx, x, index, back_index):
+        ctx.save_for_backward(back_index)
         return rows.gather(x, index)
 
     @staticmethod
     def backward(ctx, g):
-        inv_ptr, inv_idx = ctx.saved_tensors
-        return rows.pull_sum(g.contiguous(), inv_ptr, inv_idx, ctx.n_rows), None, None, None
-
-
-def _csr_inverse(index, n_rows):
-    """index (K,) long -> (ptr (n_rows + 1,), idx (K,)) int32: the list slots that hold each source row."""
-    order = torch.argsort(index, stable=True)
-    counts = torch.bincount(index, minlength=n_rows)
-    ptr = torch.cat((counts.new_zeros(1), counts.cumsum(0)))
-    return ptr.int(), order.int()
+        (back_index,) = ctx.saved_tensors
+        return rows.gather(g.contiguous(), back_index), None, None
 
 
 class DropPath(nn.Module):
@@ -109,10 +102,12 @@ class _WindowLayout:
         inv = torch.empty(n_tok + 1, dtype=torch.long)
         inv[src] = torch.arange(src.numel())
         self.scatter = inv[:n_tok].to(device)
-        # the same two lists for the row kernels: int32, with the CSR inverse each backward pulls over
+        # the same two lists for the row kernel (int32) and the list each one's adjoint gathers through: the partition
+        # reads rows 0 .. n_tok (n_tok = the zero row, whose gradient is dropped: -1), the merge reads the slots, of which
+        # the padding slots are referenced by no token (-1)
         self.gather32, self.scatter32 = self.gather.int(), self.scatter.int()
-        self.gather_inv = tuple(t.to(device) for t in _csr_inverse(src, n_tok + 1))
-        self.scatter_inv = tuple(t.to(device) for t in _csr_inverse(inv[:n_tok], src.numel()))
+        self.gather_back = torch.cat((inv[:n_tok], inv.new_full((1,), -1))).int().to(device)
+        self.scatter_back = torch.where(src < n_tok, src, torch.full_like(src, -1)).int().to(device)
         self.mask = None
         self.mask_bits = None
         if any(s > 0 for s in shift):
@@ -167,7 +162,7 @@ class WindowAttention3D(nn.Module):
         """x (B, nW, n, C) tokens per window; mask (nW, n, n) additive or None (mask_bits: the same as one bit per pair)."""
         b, nw, n, c = x.shape
         h = self.num_heads
-        if (_fast(x) and x.dtype == torch.bfloat16 and c == h * win_attn.HEAD_DIM and n <= win_attn.MAX_TOKENS
+        if (_fast(x) and x.dtype == torch.bfloat16 and c % h == 0 and c // h in win_attn.HEAD_DIMS and n <= win_attn.MAX_TOKENS
                 and (mask is None or mask_bits is not None) and not (self.training and self.attn_drop.p > 0)
                 and win_attn.ENABLED):
             # qkv projection -> ONE window-attention kernel over its output as it lies in memory -> output projection
@@ -219,9 +214,9 @@ class SwinBlock(nn.Module):
         if _fast(x) and (c * 2) % 16 == 0:
             # bf16 tokens (what the qkv projection rounds them to anyway) through the row kernels both ways
             y = torch.cat((y.to(torch.bfloat16), y.new_zeros((b, 1, c), dtype=torch.bfloat16)), dim=1)     # row n_tok: the padding token
-            y = _Rows.apply(y, lay.gather32, *lay.gather_inv).view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
+            y = _Rows.apply(y, lay.gather32, lay.gather_back).view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
             y = self.attn(y, lay.mask, lay.mask_bits)
-            y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, *lay.scatter_inv)                # merge + shift back + crop
+            y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, lay.scatter_back)                # merge + shift back + crop
             x = x + self.drop_path(y)
             return x + self.drop_path(self.mlp(self.norm2(x).to(torch.bfloat16)))
         y = torch.cat((y, y.new_zeros(b, 1, c)), dim=1)                      # row n_tok: the padding token
@@ -251,7 +246,10 @@ class PatchMerging(nn.Module):
         x = x[:, : d - d % 2]                                   # stride-2 slicing of the reference drops a last odd plane
         x = x.view(b, d // 2, 2, h // 2, 2, w // 2, 2, c)       # (b, D, dd, H, dh, W, dw, c)
         x = x.permute(0, 1, 3, 5, 2, 6, 4, 7).reshape(b, d // 2, h // 2, w // 2, 8 * c)     # blocks ordered (dd, dw, dh)
-        return self.reduction(self.norm(x))
+        y = self.norm(x)
+        if _fast(y):
+            return token_linear(y.to(torch.bfloat16), self.reduction.weight, None, force_hip=True, min_tokens=MIN_TOKENS)
+        return self.reduction(y)
 
 
 class ConvPatchMerging(nn.Module):

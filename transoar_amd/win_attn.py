@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from . import roi_attn
 
 lib = roi_attn.lib
-HEAD_DIM = 32
+HEAD_DIMS = (16, 32)          # the shipped configurations have 16 (48 / 96 / 192 / 384 channels, 3 / 6 / 12 / 24 heads)
 MAX_TOKENS = 128
 ENABLED = os.environ.get("TRANSOAR_WIN_ATTN", "1") != "0"
 
@@ -37,9 +37,9 @@ def mask_bits(mask):
 
 
 def usable(qkv, heads):
-    """qkv (B, nW, n, 3 C) bf16 on the GPU, head dimension 32, n <= 128."""
+    """qkv (B, nW, n, 3 C) bf16 on the GPU, head dimension 16 or 32, n <= 128."""
     return (ENABLED and qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 4 and qkv.shape[2] <= MAX_TOKENS
-            and qkv.shape[3] == 3 * heads * HEAD_DIM and qkv.is_contiguous())
+            and qkv.shape[3] % (3 * heads) == 0 and qkv.shape[3] // (3 * heads) in HEAD_DIMS and qkv.is_contiguous())
 
 
 class _WindowAttention(torch.autograd.Function):
@@ -53,7 +53,7 @@ class _WindowAttention(torch.autograd.Function):
         lse2 = torch.empty((windows, heads, n), dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
             roi_attn._check(lib.transoar_win_attn_forward(qkv.data_ptr(), bias_pad.data_ptr(), None if bits is None else bits.data_ptr(),
-                                                          out.data_ptr(), lse2.data_ptr(), windows, n_win, n, heads, HEAD_DIM, float(scale),
+                                                          out.data_ptr(), lse2.data_ptr(), windows, n_win, n, heads, c3 // (3 * heads), float(scale),
                                                           roi_attn._stream()), "transoar_win_attn_forward")
         ctx.save_for_backward(qkv, out, lse2, bias_pad, bits)
         ctx.heads, ctx.scale = heads, float(scale)
@@ -70,7 +70,7 @@ class _WindowAttention(torch.autograd.Function):
         with torch.cuda.device(qkv.device):
             roi_attn._check(lib.transoar_win_attn_backward(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), bias_pad.data_ptr(),
                                                            None if bits is None else bits.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), windows,
-                                                           n_win, n, ctx.heads, HEAD_DIM, ctx.scale, roi_attn._stream()),
+                                                           n_win, n, ctx.heads, c3 // (3 * ctx.heads), ctx.scale, roi_attn._stream()),
                             "transoar_win_attn_backward")
         return dqkv, dbias[:, :, :n], None, None, None
 
