@@ -29,6 +29,15 @@ enum {
 
 int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                      int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream);
+/*
+ * The same product for the two shape classes of the refinement block, dense operands (leading dimension = row length),
+ * bf16 in and out, register-stationary / tile-streaming kernels (csrc/gemm_stream.hip):
+ *   transoar_gemm_k384:  C (M, N) = A (M, 384) . B (N, 384)^T (+ bias) (ReLU);  N a multiple of 64
+ *   transoar_gemm_n384:  C (M, 384) = A (M, K) . B (384, K)^T (+ bias);          K a multiple of 32
+ */
+int transoar_gemm_k384(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu, void* hip_stream);
+int transoar_gemm_n384(const void* A, const void* B, const float* bias, void* C, int M, int K, void* hip_stream);
+
 int transoar_gemm_abi_version(void);
 
 #ifdef __cplusplus

@@ -14,8 +14,10 @@ def _ref(x, w, bias, relu):
     return y.relu() if relu else y
 
 
+# (the last five: the streaming kernels of csrc/gemm_stream.hip -- K = 384 / N = 384, >= 16 384 dense rows; odd heights)
 @pytest.mark.parametrize("m,k,n", [(1000, 384, 384), (4099, 1024, 384), (300, 384, 1024), (777, 64, 100), (128, 8, 4),
-                                    (234000, 384, 384)])
+                                    (234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (100001, 384, 576),
+                                    (100001, 768, 384)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_nt_matches_fp32_matmul(m, k, n, dt):
     if not torch.cuda.is_available():
@@ -30,6 +32,8 @@ def test_gemm_nt_matches_fp32_matmul(m, k, n, dt):
         want = _ref(x, w, bias, relu)
         got = gemm.linear_nt(x, w, bias, relu)
         assert got.dtype == dt and got.shape == (m, n)
+        if m >= 16384 and dt == torch.bfloat16:
+            assert gemm.stream_kind(x, w) == ("k384" if k == 384 else "n384")
         assert float((got.float() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6
     got32 = gemm.linear_nt(x, w, b, False, out_dtype=torch.float32)
     assert float((got32 - _ref(x, w, b, False)).abs().max()) <= 1e-5 * float(_ref(x, w, b, False).abs().max()) + 1e-6

@@ -23,15 +23,19 @@ def time_ms(fn, iters=20):
     return ts[len(ts) // 2]
 
 
-for m, k, n in ((234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (204800, 384, 384)):
+for m, k, n in ((234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (204800, 384, 384), (234000, 384, 576), (204800, 384, 3072)):
     x = torch.randn(m, k, device="cuda").bfloat16()
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()
     b = torch.randn(n, device="cuda")
     bb = b.bfloat16()
     ours = time_ms(lambda: gemm.linear_nt(x, w, b))
+    gemm.STREAM = False
+    tiled = time_ms(lambda: gemm.linear_nt(x, w, b))            # round 2's 128 x 128 LDS-tiled kernel (csrc/gemm.hip)
+    gemm.STREAM = True
     blas = time_ms(lambda: torch.nn.functional.linear(x, w, bb))
     fl = 2.0 * m * k * n
-    print(json.dumps({"M": m, "K": k, "N": n, "ours_ms": round(ours, 4), "hipblaslt_ms": round(blas, 4),
+    print(json.dumps({"M": m, "K": k, "N": n, "kernel": gemm.stream_kind(x, w) or "tiled", "ours_ms": round(ours, 4),
+                      "tiled_ms": round(tiled, 4), "hipblaslt_ms": round(blas, 4),
                       "ours_TFs": round(fl / ours / 1e9, 1), "hipblaslt_TFs": round(fl / blas / 1e9, 1),
                       "frac_of_2.5PF": round(fl / ours / 1e9 / 2500, 3)}), flush=True)
 

@@ -26,7 +26,7 @@ LIBS = {
     "libtransoar_instnorm.so": ["instnorm.hip"],
     "libtransoar_rows.so": ["rows.hip"],
     "libtransoar_tokens.so": ["tokens.hip"],
-    "libtransoar_gemm.so": ["gemm.hip"],
+    "libtransoar_gemm.so": ["gemm.hip", "gemm_stream.hip"],
     "libtransoar_convgemm.so": ["conv_gemm.hip"],
     "libtransoar_attn.so": ["attn.hip"],
 }

@@ -1,0 +1,254 @@
+// Token GEMMs with one dimension fixed at 384, register-stationary / tile-streaming form (gfx950).
+//
+// The refinement block's dense projections (transoar/models/ops/modules/ms_deform_attn.py:109-140: value_proj,
+// sampling_offsets | attention_weights, output_proj; transoar/models/backbones/decoder_blocks.py:157-174: linear1 +
+// ReLU, linear2) and their data gradients are products  C[M][N] = A[M][K] . B[N][K]^T  over M = 234 000 tokens with
+// K = 384 or N = 384.  csrc/gemm.hip's 128 x 128 LDS-tiled kernel spends a third of such a short K loop (6 steps) in
+// its prologue and epilogue and lost to hipBLASLt on the FFN shapes (0.38 / 0.27 ms against 0.27 / 0.22).  Here, with
+// the machinery of the fused attention kernels (mfma_stream.hpp):
+//
+//   gemm_k384  (K = 384: forward of every projection and of linear1, data gradient of linear2)
+//     a wave keeps ITS 32 tokens' rows of A as 24 MFMA B fragments in registers for the whole kernel; the rows of the
+//     weight stream through LDS in tiles of 32 output channels (32 x 768 bytes, LDS-DMA, two-deep ring shared by the
+//     four waves); per tile 24 MFMAs produce a complete 32 x 32 output tile C^T[n][token] (bias, ReLU in registers),
+//     which leaves through a per-wave LDS turn as whole 128-byte lines.  A is read from HBM exactly once.
+//   gemm_n384  (N = 384: forward of linear2, data gradient of linear1)
+//     a wave accumulates C^T[384][32 tokens] (192 accumulator registers) over K in chunks of 32: the weight chunk
+//     [384 rows][32 k] (24 KB, shared) and the wave's own A chunk [32 tokens][32 k] (2 KB) arrive by LDS-DMA in a
+//     four-deep ring (three chunks ahead, counted vmcnt); 24 MFMAs per chunk on 12 independent accumulators.
+//     A is read exactly once, C written once as whole 768-byte rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transoar_gemm.h"
+#include "mfma_stream.hpp"
+
+namespace transoar {
+
+// ---------------------------------------------------------------------------
+// K = 384
+// ---------------------------------------------------------------------------
+constexpr int kOutPitch = 144;                 // bytes per token row of a wave's output turn: 64 channels + 16 (bank spread)
+constexpr int kOutBytes = 32 * kOutPitch;      // 4 608 per wave
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void gemm_k384_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
+    unsigned short* __restrict__ C, int M, int N) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTile + 4 * kOutBytes];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int kh = lane >> 5;
+  FragBase fs = frag_base(lane);
+  const long m0w = static_cast<long>(blockIdx.x) * 128 + wave * 32;           // first token of this wave
+  const long m = m0w + (lane & 31);
+  s16x8 xf[kKS];
+  load_row_frags(A + (m < M ? m : M - 1) * kC, kh, xf);
+  need_frags(xf);
+  const __amdgpu_buffer_rsrc_t brs = matrix_rsrc(B, N);
+  unsigned char* outb = lds + 2 * kTile + wave * kOutBytes;
+  const int n_tiles = N >> 5;
+
+  dma_tile(brs, 0u, lds, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const int st = t & 1;
+    if (t + 1 < n_tiles) dma_tile(brs, static_cast<unsigned>(t + 1) * kTile, lds + (st ^ 1) * kTile, wave, lane);
+    // C^T[n][token] of the tile: two accumulators, weight fragments fetched six K steps ahead
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    {
+      s16x8 fw[2][6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) fw[0][e] = frag_rows<0>(lds, fs, e);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        if (gq + 1 < 4) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) fw[(gq + 1) & 1][e] = frag_rows<0>(lds, fs, 6 * (gq + 1) + e);
+        }
+#pragma unroll
+        for (int e = 0; e < 6; e += 2) {
+          c0 = mfma(fw[gq & 1][e], xf[6 * gq + e], c0);
+          c1 = mfma(fw[gq & 1][e + 1], xf[6 * gq + e + 1], c1);
+        }
+      }
+    }
+    // bias (wave-uniform address: scalar loads), ReLU, bf16 -> the wave's output turn: entry r = channel
+    // 32 t + (r & 3) + 8 (r >> 2) + 4 kh of token lane & 31
+    {
+      const float* bt = bias + 32 * t;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float b = 0.f;
+          if (bias != nullptr) b = kh ? bt[8 * qd + 4 + e] : bt[8 * qd + e];
+          v[e] = c0[4 * qd + e] + c1[4 * qd + e] + b;
+          if (RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<u32x2*>(outb + (lane & 31) * kOutPitch + 2 * (32 * (t & 1) + 8 * qd + 4 * kh)) =
+            u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+      }
+    }
+    frag_shift(fs, st ? -kTile : kTile);
+    dma_wait();
+    __syncthreads();
+    if (t & 1) {
+      // two tiles = 64 channels = one 128-byte line per token: 8 tokens per store instruction
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), piece = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(outb + row * kOutPitch + piece * 16);
+        if (m0w + row < M) *reinterpret_cast<u32x4*>(C + (m0w + row) * N + 32 * (t - 1) + 8 * piece) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// N = 384
+// ---------------------------------------------------------------------------
+constexpr int kChunkK = 32;                                  // K elements per chunk
+constexpr int kWChunk = kC * kChunkK * 2;                    // 24 576: [384 rows][64 bytes]
+constexpr int kAChunk = 32 * kChunkK * 2;                    // 2 048 per wave: [32 tokens][64 bytes]
+constexpr int kStage = kWChunk + 4 * kAChunk;                // 32 768
+constexpr int kRing = 4;
+constexpr int kRowPitchOut = kRowBytes + 16;                 // 784: output turn [32 tokens][384] per wave
+
+// [rows][64 bytes] chunk, 16 rows per 1-KiB DMA piece: lane = (row in piece, 16-byte piece q); the four pieces of a
+// row are XORed with (row >> 2) & 3 (conflict-free ds_read_b128 of 16 rows)
+__device__ __forceinline__ void dma_chunk_piece(__amdgpu_buffer_rsrc_t rs, unsigned base_byte, int row0, unsigned row_bytes,
+                                                unsigned char* lds_piece, int lane) {
+  const int row = row0 + (lane >> 2), q = lane & 3;
+  const int voff = row * static_cast<int>(row_bytes) + ((q ^ ((row >> 2) & 3)) << 4);
+  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_piece)));
+  const unsigned soff = __builtin_amdgcn_readfirstlane(base_byte);
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+      : "memory");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_n384_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
+    unsigned short* __restrict__ C, int M, int K) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * kStage];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int kh = lane >> 5;
+  const long m0w = static_cast<long>(blockIdx.x) * 128 + wave * 32;
+  const unsigned row_bytes = static_cast<unsigned>(K) * 2u;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, static_cast<int>(static_cast<long>(M) * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, static_cast<int>(static_cast<long>(kC) * K * 2), 0x00020000);
+  const unsigned a_base = static_cast<unsigned>(m0w) * row_bytes;            // < 2^32: checked by the host
+  // fragment offsets inside a chunk: row (lane & 31) (+ 32 ct for the weight), K step ks of the chunk
+  int fb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) fb[ks] = (lane & 31) * 64 + (((2 * ks + kh) ^ (((lane & 31) >> 2) & 3)) << 4);
+  f32x16 acc[kCT];
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const int n_chunks = K / kChunkK;
+  auto issue = [&](int c) {                    // 8 DMA instructions per wave: 6 pieces of the weight chunk, 2 of its own A chunk
+    unsigned char* stg = lds + (c & (kRing - 1)) * kStage;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dma_chunk_piece(brs, static_cast<unsigned>(c) * 64u, 16 * (6 * wave + j), row_bytes, stg + (6 * wave + j) * 1024, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma_chunk_piece(ars, a_base + static_cast<unsigned>(c) * 64u, 16 * j, row_bytes, stg + kWChunk + wave * kAChunk + j * 1024, lane);
+  };
+  // the waits count DMA instructions (8 per chunk and wave, in issue order): chunk c has landed when at most the
+  // instructions of the chunks issued after it are outstanding
+  issue(0);
+  if (n_chunks > 1) issue(1);
+  if (n_chunks > 2) issue(2);
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c + 3 < n_chunks) {
+      issue(c + 3);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    } else if (c + 2 < n_chunks) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (c + 1 < n_chunks) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();               // every wave's pieces of chunk c have landed (a bare barrier: no vmcnt(0) drain)
+    int so = (c & (kRing - 1)) * kStage;
+    asm volatile("" : "+s"(so));
+    const unsigned char* wt = lds + so;
+    const unsigned char* at = wt + kWChunk + wave * kAChunk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const s16x8 bfr = *reinterpret_cast<const s16x8*>(at + fb[ks]);
+#pragma unroll
+      for (int ct = 0; ct < kCT; ++ct)
+        acc[ct] = mfma(*reinterpret_cast<const s16x8*>(wt + fb[ks] + ct * 2048), bfr, acc[ct]);
+    }
+    // the stage is overwritten by chunk c + 4, issued at the top of iteration c + 1: all reads of it must be done
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- C^T[n][token] + bias -> the wave's LDS turn [token][384] -> whole rows
+  unsigned char* outb = lds + wave * (32 * kRowPitchOut);
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = 32 * ct + 8 * qd + 4 * kh;
+      float4 b4{0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) b4 = *reinterpret_cast<const float4*>(bias + n);
+      *reinterpret_cast<u32x2*>(outb + (lane & 31) * kRowPitchOut + 2 * n) =
+          u32x2{pack_bf16(acc[ct][4 * qd] + b4.x, acc[ct][4 * qd + 1] + b4.y), pack_bf16(acc[ct][4 * qd + 2] + b4.z, acc[ct][4 * qd + 3] + b4.w)};
+    }
+#pragma unroll
+  for (int it = 0; it < 24; ++it) {
+    const int e = it * 64 + lane;               // 16-byte piece e of the wave's 32 rows x 48 pieces
+    const int row = (e * 683) >> 15;            // e / 48 for e < 1536
+    const int pc = e - row * 48;
+    if (m0w + row < M)
+      *reinterpret_cast<u32x4*>(C + (m0w + row) * kC + 8 * pc) = *reinterpret_cast<const u32x4*>(outb + row * kRowPitchOut + pc * 16);
+  }
+}
+
+}  // namespace transoar
+
+using namespace transoar;
+
+extern "C" int transoar_gemm_k384(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu, void* hip_stream) {
+  if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
+  if (M <= 0 || N <= 0 || (N & 63)) return TRANSOAR_GEMM_ERR_DIM;
+  if (static_cast<long>(N) * kRowBytes >= 0x7ffffff0L || static_cast<long>(M) * N * 2 >= (1L << 40)) return TRANSOAR_GEMM_ERR_DIM;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15u)
+    return TRANSOAR_GEMM_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(static_cast<unsigned>((M + 127) / 128));
+  auto a = static_cast<const unsigned short*>(A);
+  auto b = static_cast<const unsigned short*>(B);
+  auto c = static_cast<unsigned short*>(C);
+  if (relu) hipLaunchKernelGGL(gemm_k384_kernel<true>, grid, dim3(256), 0, st, a, b, bias, c, M, N);
+  else hipLaunchKernelGGL(gemm_k384_kernel<false>, grid, dim3(256), 0, st, a, b, bias, c, M, N);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_gemm_n384(const void* A, const void* B, const float* bias, void* C, int M, int K, void* hip_stream) {
+  if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
+  if (M <= 0 || K <= 0 || (K & 31)) return TRANSOAR_GEMM_ERR_DIM;
+  if ((static_cast<long>(M) + 128) * K * 2 >= 0xffffffffL || static_cast<long>(kC) * K * 2 >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;     // 32-bit byte offsets into A
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15u)
+    return TRANSOAR_GEMM_ERR_ALIGN;
+  hipLaunchKernelGGL(gemm_n384_kernel, dim3(static_cast<unsigned>((M + 127) / 128)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(B), bias, static_cast<unsigned short*>(C), M, K);
+  return static_cast<int>(hipGetLastError());
+}

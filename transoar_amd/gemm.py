@@ -10,7 +10,8 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
+STREAM = os.environ.get("TRANSOAR_GEMM_STREAM", "1") != "0"      # the K = 384 / N = 384 streaming kernels (csrc/gemm_stream.hip)
 _DT = {torch.float32: 0, torch.bfloat16: 2, torch.float16: 3}
 
 
@@ -21,6 +22,10 @@ def _load():
     i, p = ctypes.c_int, ctypes.c_void_p
     lib.transoar_gemm_nt.restype = i
     lib.transoar_gemm_nt.argtypes = [p, p, p, p] + [i] * 9 + [p]
+    lib.transoar_gemm_k384.restype = i
+    lib.transoar_gemm_k384.argtypes = [p, p, p, p, i, i, i, p]
+    lib.transoar_gemm_n384.restype = i
+    lib.transoar_gemm_n384.argtypes = [p, p, p, p, i, i, p]
     lib.transoar_gemm_abi_version.restype = i
     if lib.transoar_gemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -38,6 +43,22 @@ def usable(x, w):
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and x.shape[0] * x.stride(0) * 2 < 0x7ffffff0)
 
 
+def stream_kind(x, w, out_dtype=None, relu=False):
+    """Which streaming kernel takes this product (None: the generic tiled kernel): bf16, dense operands, K = 384 with
+    N % 64 == 0, or N = 384 with K % 32 == 0 (no ReLU there), tall enough to fill the chip."""
+    if not STREAM or x.dtype != torch.bfloat16 or (out_dtype or x.dtype) != torch.bfloat16:
+        return None
+    m, k = x.shape
+    n = w.shape[0]
+    if not (x.is_contiguous() and w.is_contiguous() and m >= 16384):
+        return None
+    if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0:
+        return "k384"
+    if n == 384 and k % 32 == 0 and k != 384 and (m + 128) * k * 2 < 0xffffffff:
+        return "n384"
+    return None
+
+
 def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
     """x (M, K), w (N, K) -> (M, N) = x @ w.T (+ bias) (ReLU); bias fp32 (N,)."""
     if not usable(x, w):
@@ -48,6 +69,20 @@ def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
     out = torch.empty((m, n), dtype=out_dtype, device=x.device)
     if bias is not None:
         bias = bias.float().contiguous()
+    kind = stream_kind(x, w, out_dtype)
+    if kind == "n384" and relu:
+        kind = None
+    if kind is not None:
+        with torch.cuda.device(x.device):
+            bp = None if bias is None else bias.data_ptr()
+            if kind == "k384":
+                rc = lib.transoar_gemm_k384(x.data_ptr(), w.data_ptr(), bp, out.data_ptr(), m, n, 1 if relu else 0,
+                                            torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = lib.transoar_gemm_n384(x.data_ptr(), w.data_ptr(), bp, out.data_ptr(), m, k, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_gemm_%s failed with code %d" % (kind, rc))
+        return out
     with torch.cuda.device(x.device):
         rc = lib.transoar_gemm_nt(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
                                   m, n, k, x.stride(0), w.stride(0), n, _DT[x.dtype], _DT[out_dtype], 1 if relu else 0,

@@ -36,7 +36,9 @@ def _hip_gemm(x2, w, force=False):
         return False
     if USE_HIP_GEMM is not None:
         return USE_HIP_GEMM
-    return force or (x2.shape[1] == 384 and w.shape[0] == 384)
+    # K = N = 384 on the tiled kernel (round 2); every K = 384 or N = 384 product of >= 16 384 tokens on the streaming
+    # kernels of csrc/gemm_stream.hip (round 4: the FFN shapes 384 -> 1024 -> 384 and their data gradients included)
+    return force or (x2.shape[1] == 384 and w.shape[0] == 384) or gemm.stream_kind(x2, w) is not None
 
 
 def _chunks(tokens, n_out, n_in):
