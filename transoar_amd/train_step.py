@@ -169,13 +169,13 @@ class TrainStep:
                     self.optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        from . import GRAPH_REPLAY_SAFE
-        if not GRAPH_REPLAY_SAFE and not os.environ.get("TRANSOAR_TRUST_PACKET_CAPTURE"):
+        from . import graph_replay_safe
+        if not graph_replay_safe() and not os.environ.get("TRANSOAR_TRUST_PACKET_CAPTURE"):
             if snap is not None:
                 self._restore(snap)
             raise RuntimeError("HIP was initialised with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: this ROCm's pre-recorded "
                                "graph packets corrupt the replayed step (DESIGN.md section 8); export "
-                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or import transoar_amd before the first HIP call")
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process, or call transoar_amd.use_safe_graph_replay() before the first HIP call")
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
