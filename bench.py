@@ -286,7 +286,8 @@ def main():
         try:
             step.capture(x, targets)
             step(x, targets)                   # first replay: TrainStep checks its loss against the eager step's
-            step_mode = ("hip-graph(fwd+loss+bwd+AdamW)" if step.capture_optimizer else
+            step_mode = ("hip-graph(fwd+loss+bwd+all-reduce+AdamW)" if getattr(step, "capture_exchange", False) and step.capture_optimizer else
+                         "hip-graph(fwd+loss+bwd+AdamW)" if step.capture_optimizer else
                          "hip-graph(fwd+loss+bwd) + eager all-reduce + fused AdamW")
         except Exception as e:                 # keep going eagerly, say so in the output
             import traceback

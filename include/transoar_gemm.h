@@ -37,6 +37,11 @@ int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, i
  */
 int transoar_gemm_k384(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu, void* hip_stream);
 int transoar_gemm_n384(const void* A, const void* B, const float* bias, void* C, int M, int K, void* hip_stream);
+/* transoar_gemm_k384 with seeded dropout in the epilogue: y = keep ? act(x W^T + b) * keep_scale : 0, the mask of
+ * csrc/tokens.hip's relu_dropout (element pair p kept where the 16-bit halves of hash32(p * 0x9e3779b9 + *drop_seed) are
+ * below keep_prob * 2^16): decoder_blocks.py:166's dropout(activation(linear1(x))) in one kernel.  drop_seed: device int. */
+int transoar_gemm_k384_drop(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu,
+                            const int* drop_seed, float keep_prob, float keep_scale, void* hip_stream);
 
 int transoar_gemm_abi_version(void);
 

@@ -32,7 +32,7 @@ def test_gemm_nt_matches_fp32_matmul(m, k, n, dt):
         want = _ref(x, w, bias, relu)
         got = gemm.linear_nt(x, w, bias, relu)
         assert got.dtype == dt and got.shape == (m, n)
-        if m >= 16384 and dt == torch.bfloat16:
+        if m >= 16384 and dt == torch.bfloat16 and not (k == 384 and n == 384):
             assert gemm.stream_kind(x, w) == ("k384" if k == 384 else "n384")
         assert float((got.float() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6
     got32 = gemm.linear_nt(x, w, b, False, out_dtype=torch.float32)
@@ -78,3 +78,55 @@ def test_token_linear_runs_on_the_hand_written_gemm():
     assert rel(lin.weight.grad, wr.grad) <= 2e-3
     assert rel(lin.bias.grad, gy.float().sum((0, 1))) <= 1e-3
     tl.USE_HIP_GEMM = None
+
+
+def test_streaming_k384_square_and_fused_relu_dropout():
+    """The K = 384 streaming kernel on the square projection shape (not its default there) and with bias + ReLU + seeded
+    dropout in its epilogue: the mask is the one tokens.relu_dropout derives from the same seed (tokens.hashed_keep), so
+    the fused linear1 equals relu_dropout(linear) up to the GEMMs' output rounding; its autograd against fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd import gemm, token_linear as tl, tokens
+    g = torch.Generator(device="cuda").manual_seed(5)
+    m = 50001
+    x = torch.randn(m, 384, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(1024, 384, device="cuda", generator=g) / 384 ** 0.5).to(torch.bfloat16)
+    b = torch.randn(1024, device="cuda", generator=g)
+    gemm.STREAM_SQUARE = True
+    try:
+        w2 = w[:384].contiguous()
+        assert gemm.stream_kind(x, w2) == "k384"
+        got = gemm.linear_nt(x, w2, b[:384])
+        want = _ref(x, w2, b[:384], False)
+        assert float((got.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    finally:
+        gemm.STREAM_SQUARE = False
+    seed = tokens.dropout_seed(x)
+    keep_prob = 0.9
+    y = gemm.linear_relu_dropout(x, w, b, seed, keep_prob)
+    keep = tokens.hashed_keep(seed, m * 1024, keep_prob).view(m, 1024).float()
+    want = _ref(x, w, b, True) * keep / keep_prob
+    assert float((y.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    assert torch.equal(y == 0, (want == 0) | (y == 0))                  # dropped elements are exactly zero
+    assert abs(float(keep.mean()) - keep_prob) < 2e-3
+    # autograd of the fused layer (module interface) against fp32 with the same mask
+    lin = torch.nn.Linear(384, 1024).cuda()
+    drop = torch.nn.Dropout(0.1).train()
+    xg = x.clone().requires_grad_()
+    torch.manual_seed(11)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert tl.linear_relu_dropout_usable(xg, lin.weight)
+        yy = tl.linear_relu_dropout(xg, lin.weight, lin.bias, drop)
+    gy = torch.randn(yy.shape, device="cuda", generator=g).to(torch.bfloat16)
+    yy.backward(gy)
+    torch.manual_seed(11)
+    seed2 = tokens.dropout_seed(x)                                         # the seed the call above drew
+    keep2 = tokens.hashed_keep(seed2, m * 1024, 0.9).view(m, 1024).float()
+    xr = x.float().requires_grad_()
+    wr = lin.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    yr = torch.relu(torch.nn.functional.linear(xr, wr, lin.bias.detach())) * keep2 / 0.9
+    yr.backward(gy.float())
+    rel = lambda a, c: float((a.float() - c).abs().max() / c.abs().max())
+    assert rel(yy, yr) <= 2.0 ** -7
+    assert rel(xg.grad, xr.grad) <= 2.0 ** -6
+    assert rel(lin.weight.grad, wr.grad) <= 3e-3

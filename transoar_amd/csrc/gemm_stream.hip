@@ -15,7 +15,8 @@
 //   gemm_n384  (N = 384: forward of linear2, data gradient of linear1)
 //     a wave accumulates C^T[384][32 tokens] (192 accumulator registers) over K in chunks of 32: the weight chunk
 //     [384 rows][32 k] (24 KB, shared) and the wave's own A chunk [32 tokens][32 k] (2 KB) arrive by LDS-DMA in a
-//     four-deep ring (three chunks ahead, counted vmcnt); 24 MFMAs per chunk on 12 independent accumulators.
+//     five-deep ring (three chunks ahead, counted vmcnt, one bare barrier per chunk); 24 MFMAs per chunk on 12
+//     independent accumulators.
 //     A is read exactly once, C written once as whole 768-byte rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,10 +32,18 @@ namespace transoar {
 constexpr int kOutPitch = 144;                 // bytes per token row of a wave's output turn: 64 channels + 16 (bank spread)
 constexpr int kOutBytes = 32 * kOutPitch;      // 4 608 per wave
 
-template <bool RELU>
+// seeded dropout of csrc/tokens.hip (keep_pair): element pair p = (flat element index) / 2 is kept where the 16-bit halves
+// of hash32(p * 0x9e3779b9 + seed) are below thr16 (low half: the even element)
+__device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned seed) {
+  unsigned x = pair * 0x9e3779b9u + seed;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+template <bool RELU, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_k384_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
-    unsigned short* __restrict__ C, int M, int N) {
+    unsigned short* __restrict__ C, int M, int N, const int* __restrict__ drop_seed, unsigned thr16, float drop_scale) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTile + 4 * kOutBytes];
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
@@ -45,6 +54,12 @@ __global__ __launch_bounds__(256, 2) void gemm_k384_kernel(
   load_row_frags(A + (m < M ? m : M - 1) * kC, kh, xf);
   need_frags(xf);
   const __amdgpu_buffer_rsrc_t brs = matrix_rsrc(B, N);
+  unsigned seed = 0u;
+  if (DROP) {
+    seed = static_cast<unsigned>(*drop_seed);
+    need(seed);
+  }
+  const unsigned pair_row = static_cast<unsigned>(m) * static_cast<unsigned>(N >> 1);        // pair index of (token m, channel 0)
   unsigned char* outb = lds + 2 * kTile + wave * kOutBytes;
   const int n_tiles = N >> 5;
 
@@ -89,6 +104,14 @@ __global__ __launch_bounds__(256, 2) void gemm_k384_kernel(
           v[e] = c0[4 * qd + e] + c1[4 * qd + e] + b;
           if (RELU) v[e] = fmaxf(v[e], 0.f);
         }
+        if (DROP) {                               // channels 32 t + 8 qd + 4 kh .. + 3 = two element pairs
+          const unsigned p0 = pair_row + static_cast<unsigned>(16 * t + 4 * qd + 2 * kh);
+          const unsigned h0 = drop_hash(p0, seed), h1 = drop_hash(p0 + 1u, seed);
+          v[0] = (h0 & 0xffffu) < thr16 ? v[0] * drop_scale : 0.f;
+          v[1] = (h0 >> 16) < thr16 ? v[1] * drop_scale : 0.f;
+          v[2] = (h1 & 0xffffu) < thr16 ? v[2] * drop_scale : 0.f;
+          v[3] = (h1 >> 16) < thr16 ? v[3] * drop_scale : 0.f;
+        }
         *reinterpret_cast<u32x2*>(outb + (lane & 31) * kOutPitch + 2 * (32 * (t & 1) + 8 * qd + 4 * kh)) =
             u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
       }
@@ -115,7 +138,7 @@ constexpr int kChunkK = 32;                                  // K elements per c
 constexpr int kWChunk = kC * kChunkK * 2;                    // 24 576: [384 rows][64 bytes]
 constexpr int kAChunk = 32 * kChunkK * 2;                    // 2 048 per wave: [32 tokens][64 bytes]
 constexpr int kStage = kWChunk + 4 * kAChunk;                // 32 768
-constexpr int kRing = 4;
+constexpr int kRing = 5;                                     // 5 x 32 KiB = all of the CU's LDS: one workgroup per CU
 constexpr int kRowPitchOut = kRowBytes + 16;                 // 784: output turn [32 tokens][384] per wave
 
 // [rows][64 bytes] chunk, 16 rows per 1-KiB DMA piece: lane = (row in piece, 16-byte piece q); the four pieces of a
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int n_chunks = K / kChunkK;
   auto issue = [&](int c) {                    // 8 DMA instructions per wave: 6 pieces of the weight chunk, 2 of its own A chunk
-    unsigned char* stg = lds + (c & (kRing - 1)) * kStage;
+    unsigned char* stg = lds + (c % kRing) * kStage;
 #pragma unroll
     for (int j = 0; j < 6; ++j) dma_chunk_piece(brs, static_cast<unsigned>(c) * 64u, 16 * (6 * wave + j), row_bytes, stg + (6 * wave + j) * 1024, lane);
 #pragma unroll
@@ -184,8 +207,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();               // every wave's pieces of chunk c have landed (a bare barrier: no vmcnt(0) drain)
-    int so = (c & (kRing - 1)) * kStage;
+    // every wave's pieces of chunk c have landed (a bare barrier: no vmcnt(0) drain).  ONE barrier per chunk: the stage
+    // read here is overwritten by chunk c + 5, issued at the top of iteration c + 2 by a wave that has passed barrier
+    // c + 1, which every wave reaches only after its reads of this iteration
+    __builtin_amdgcn_s_barrier();
+    int so = (c % kRing) * kStage;
     asm volatile("" : "+s"(so));
     const unsigned char* wt = lds + so;
     const unsigned char* at = wt + kWChunk + wave * kAChunk;
@@ -196,10 +222,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int ct = 0; ct < kCT; ++ct)
         acc[ct] = mfma(*reinterpret_cast<const s16x8*>(wt + fb[ks] + ct * 2048), bfr, acc[ct]);
     }
-    // the stage is overwritten by chunk c + 4, issued at the top of iteration c + 1: all reads of it must be done
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // the ring becomes the output turn
   // ---- C^T[n][token] + bias -> the wave's LDS turn [token][384] -> whole rows
   unsigned char* outb = lds + wave * (32 * kRowPitchOut);
 #pragma unroll
@@ -226,7 +251,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 using namespace transoar;
 
+static unsigned drop_threshold(float keep_prob) {          // csrc/tokens.hip: keep_threshold
+  const float t = keep_prob * 65536.f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : static_cast<unsigned>(t));
+}
+
+extern "C" int transoar_gemm_k384_drop(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu,
+                                       const int* drop_seed, float keep_prob, float keep_scale, void* hip_stream);
+
 extern "C" int transoar_gemm_k384(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu, void* hip_stream) {
+  return transoar_gemm_k384_drop(A, B, bias, C, M, N, relu, nullptr, 1.f, 1.f, hip_stream);
+}
+
+extern "C" int transoar_gemm_k384_drop(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu,
+                                       const int* drop_seed, float keep_prob, float keep_scale, void* hip_stream) {
   if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
   if (M <= 0 || N <= 0 || (N & 63)) return TRANSOAR_GEMM_ERR_DIM;
   if (static_cast<long>(N) * kRowBytes >= 0x7ffffff0L || static_cast<long>(M) * N * 2 >= (1L << 40)) return TRANSOAR_GEMM_ERR_DIM;
@@ -237,8 +275,15 @@ extern "C" int transoar_gemm_k384(const void* A, const void* B, const float* bia
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
   auto c = static_cast<unsigned short*>(C);
-  if (relu) hipLaunchKernelGGL(gemm_k384_kernel<true>, grid, dim3(256), 0, st, a, b, bias, c, M, N);
-  else hipLaunchKernelGGL(gemm_k384_kernel<false>, grid, dim3(256), 0, st, a, b, bias, c, M, N);
+  if (static_cast<long>(M) * (N >> 1) >= (1L << 32)) return TRANSOAR_GEMM_ERR_DIM;          // 32-bit pair indices of the dropout hash
+  const unsigned thr = drop_threshold(keep_prob);
+  if (drop_seed != nullptr) {
+    if (relu) hipLaunchKernelGGL((gemm_k384_kernel<true, true>), grid, dim3(256), 0, st, a, b, bias, c, M, N, drop_seed, thr, keep_scale);
+    else hipLaunchKernelGGL((gemm_k384_kernel<false, true>), grid, dim3(256), 0, st, a, b, bias, c, M, N, drop_seed, thr, keep_scale);
+  } else {
+    if (relu) hipLaunchKernelGGL((gemm_k384_kernel<true, false>), grid, dim3(256), 0, st, a, b, bias, c, M, N, drop_seed, thr, keep_scale);
+    else hipLaunchKernelGGL((gemm_k384_kernel<false, false>), grid, dim3(256), 0, st, a, b, bias, c, M, N, drop_seed, thr, keep_scale);
+  }
   return static_cast<int>(hipGetLastError());
 }
 

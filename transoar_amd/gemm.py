@@ -11,6 +11,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
 ABI_VERSION = 2
+STREAM_SQUARE = os.environ.get("TRANSOAR_GEMM_STREAM_SQUARE", "0") == "1"
 STREAM = os.environ.get("TRANSOAR_GEMM_STREAM", "1") != "0"      # the K = 384 / N = 384 streaming kernels (csrc/gemm_stream.hip)
 _DT = {torch.float32: 0, torch.bfloat16: 2, torch.float16: 3}
 
@@ -24,6 +25,8 @@ def _load():
     lib.transoar_gemm_nt.argtypes = [p, p, p, p] + [i] * 9 + [p]
     lib.transoar_gemm_k384.restype = i
     lib.transoar_gemm_k384.argtypes = [p, p, p, p, i, i, i, p]
+    lib.transoar_gemm_k384_drop.restype = i
+    lib.transoar_gemm_k384_drop.argtypes = [p, p, p, p, i, i, i, p, ctypes.c_float, ctypes.c_float, p]
     lib.transoar_gemm_n384.restype = i
     lib.transoar_gemm_n384.argtypes = [p, p, p, p, i, i, p]
     lib.transoar_gemm_abi_version.restype = i
@@ -52,8 +55,8 @@ def stream_kind(x, w, out_dtype=None, relu=False):
     n = w.shape[0]
     if not (x.is_contiguous() and w.is_contiguous() and m >= 16384):
         return None
-    if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0:
-        return "k384"
+    if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE):
+        return "k384"            # (384 x 384: the tiled kernel measures 0.149 ms against 0.158, profiles/r04_gemm_bench.jsonl)
     if n == 384 and k % 32 == 0 and k != 384 and (m + 128) * k * 2 < 0xffffffff:
         return "n384"
     return None
@@ -89,4 +92,23 @@ def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
                                   torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("transoar_gemm_nt failed with code %d" % rc)
+    return out
+
+
+def linear_relu_dropout(x, w, bias, seed, keep_prob):
+    """dropout(relu(x @ w.T + bias)) in one kernel (K = 384 streaming GEMM with the seeded mask of tokens.relu_dropout in
+    its epilogue).  x (M, 384), w (N, 384) bf16 dense, bias fp32 or None, seed: device int32 tensor (tokens.dropout_seed)
+    or None (no dropout)."""
+    if stream_kind(x, w) != "k384":
+        raise RuntimeError("linear_relu_dropout: needs the K = 384 streaming kernel (dense bf16 operands, >= 16384 rows)")
+    m, n = x.shape[0], w.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_gemm_k384_drop(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), m, n, 1,
+                                         None if seed is None else seed.data_ptr(), float(keep_prob), 1.0 / float(keep_prob),
+                                         torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_k384_drop failed with code %d" % rc)
     return out

@@ -17,7 +17,9 @@ import torch.nn.functional as F
 from torch import nn
 
 from .ms_deform_attn import MSDeformAttn
-from .token_linear import token_linear
+from .token_linear import linear_relu_dropout, linear_relu_dropout_usable, token_linear
+
+FUSED_FFN1 = os.environ.get("TRANSOAR_FUSED_FFN1", "1") != "0"      # linear1 + ReLU + dropout as one GEMM launch
 from . import tokens as fused_tokens
 from .position_encoding import is_constant
 
@@ -99,11 +101,16 @@ class DefAttnLayer(nn.Module):
         level_start) asks for the next layer's query.  -> (y32, y16, q16 or None)"""
         attn = self.self_attn(q16, reference_points, x16, spatial_shapes, level_start_index)
         y32, y16, _ = fused_tokens.add_layernorm(x, attn.contiguous(), self.norm1, dropout=self.dropout1)
-        hidden = token_linear(y16, self.linear1.weight, self.linear1.bias)
-        if self.activation is F.relu and hidden.dtype == torch.bfloat16 and hidden.numel() % 8 == 0:
-            hidden = fused_tokens.relu_dropout(hidden, self.dropout2)
+        if (self.activation is F.relu and fused_tokens.SEEDED_DROPOUT and FUSED_FFN1
+                and linear_relu_dropout_usable(y16, self.linear1.weight)):
+            # linear1 + bias + ReLU + dropout in ONE kernel (the K = 384 streaming GEMM's epilogue)
+            hidden = linear_relu_dropout(y16, self.linear1.weight, self.linear1.bias, self.dropout2)
         else:
-            hidden = self.dropout2(self.activation(hidden))
+            hidden = token_linear(y16, self.linear1.weight, self.linear1.bias)
+            if self.activation is F.relu and hidden.dtype == torch.bfloat16 and hidden.numel() % 8 == 0:
+                hidden = fused_tokens.relu_dropout(hidden, self.dropout2)
+            else:
+                hidden = self.dropout2(self.activation(hidden))
         ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
         return fused_tokens.add_layernorm(y32, ffn.contiguous(), self.norm2, *pos_pack, dropout=self.dropout3)
 

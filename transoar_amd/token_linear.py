@@ -120,6 +120,62 @@ class _TokenLinear(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class _LinearReluDropout(torch.autograd.Function):
+    """dropout(relu(x W^T + b)) with bias, ReLU and the seeded dropout mask in the epilogue of the K = 384 streaming GEMM
+    (decoder_blocks.py:166: ``self.dropout2(self.activation(self.linear1(src)))``): the 480-MB hidden tensor is written
+    once instead of written, re-read and re-written.  The backward needs only the output (y > 0 <=> kept and pre-activation
+    > 0): gh = y > 0 ? gy * scale : 0 (tokens' relu_dropout_backward), then the data / weight / bias gradients as usual."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, seed, keep_prob):
+        xb = x.to(torch.bfloat16)
+        wb = shadow.bf16_or_cast(weight)
+        x2 = xb.reshape(-1, xb.shape[-1])
+        y = gemm.linear_relu_dropout(x2, wb, bias, seed, keep_prob)
+        ctx.save_for_backward(xb, wb, y)
+        ctx.in_dtype, ctx.has_bias, ctx.scale = x.dtype, bias is not None, 1.0 / keep_prob
+        return y.view(*xb.shape[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import tokens
+        xb, wb, y = ctx.saved_tensors
+        gy2 = gy.to(torch.bfloat16).reshape(-1, gy.shape[-1]).contiguous()
+        gh = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = tokens.lib.transoar_relu_dropout_backward(gy2.data_ptr(), y.data_ptr(), ctx.scale, gh.data_ptr(), y.numel(),
+                                                           torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("transoar_relu_dropout_backward failed with code %d" % rc)
+        gx = gw = gb = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                wt = wb.t().contiguous()
+                gx = gemm.linear_nt(gh, wt).view(xb.shape).to(ctx.in_dtype)
+            if ctx.needs_input_grad[1]:
+                gw = weight_grad(gh, xb.reshape(-1, xb.shape[-1]))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = rows.colsum_any(gh)
+        return gx, gw, gb, None, None
+
+
+def linear_relu_dropout_usable(x, weight):
+    """The fused linear1 of the refinement block: bf16 autocast on the GPU, 384 input channels, dense tokens."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.float32
+            and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+        return False
+    x2 = x.reshape(-1, x.shape[-1])
+    return USE_HIP_GEMM is not False and x2.shape[1] == 384 and x2.shape[0] >= 16384 and weight.shape[0] % 64 == 0 and gemm.STREAM
+
+
+def linear_relu_dropout(x, weight, bias, dropout):
+    """dropout(relu(linear(x))) in one GEMM launch; `dropout`: the nn.Dropout module (its p and training flag)."""
+    from . import tokens
+    active = dropout.training and dropout.p > 0.0
+    seed = tokens.dropout_seed(x) if active else None
+    return _LinearReluDropout.apply(x, weight, bias, seed, 1.0 - dropout.p if active else 1.0)
+
+
 def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None, weight2=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
     bf16 autocast on the GPU with enough tokens, the stock one otherwise.  force_hip: the hand-written GEMM for

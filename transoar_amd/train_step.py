@@ -44,8 +44,13 @@ class TrainStep:
         # one rank + graph: the AdamW update is captured too (the whole step is one graph launch); with several
         # ranks the gradient exchange sits between backward and update, which stays eager
         single = not (torch.distributed.is_available() and torch.distributed.is_initialized())
-        self.capture_optimizer = bool(graph and single and optimizer is None and os.environ.get("TRANSOAR_EAGER_OPTIMIZER") is None
-                                      and next(model.parameters()).is_cuda)
+        # several ranks + graph (round 4): the bucket all-reduces are captured too -- launched by the gradient hooks from
+        # inside the captured backward (RCCL's stream forks off the capture stream: a parallel branch of the graph that
+        # overlaps the rest of the backward), joined before the captured AdamW.  TRANSOAR_DP_CAPTURE_EXCHANGE=0: round 3's
+        # form (graph = fwd + loss + bwd, then an eager exchange and an eager AdamW: the whole exchange exposed).
+        self.capture_exchange = bool(graph and not single and os.environ.get("TRANSOAR_DP_CAPTURE_EXCHANGE", "1") != "0")
+        self.capture_optimizer = bool(graph and (single or self.capture_exchange) and optimizer is None
+                                      and os.environ.get("TRANSOAR_EAGER_OPTIMIZER") is None and next(model.parameters()).is_cuda)
         self.optimizer = optimizer or build_optimizer(model, config, capturable=self.capture_optimizer)
         # scripts/train.py:65: StepLR(optim, lr_drop), stepped once per EPOCH (trainer.py:220) -> end_epoch()
         self.scheduler = scheduler if scheduler is not None or "lr_drop" not in config else \
@@ -147,7 +152,7 @@ class TrainStep:
         self._static_counts = self._local_counts(self._static_t)
         if self.reducer.active:      # ... rank-summed
             self.reducer.reduce_counts(self._static_counts)
-        self.reducer.overlap = False
+        self.reducer.overlap = self.capture_exchange       # hooks launch the buckets' all-reduces only when they are captured
         # warm-up AND capture on one and the same side stream: autograd's AccumulateGrad nodes remember the
         # stream of the first backward; if the capture runs on another stream the engine inserts cross-stream
         # waits into the captured graph (the "AccumulateGrad node's stream does not match" warning)
@@ -164,6 +169,8 @@ class TrainStep:
                     eager_total = total          # the loss on the weights capture() was called with
                     if self.reducer.active:
                         self.reducer._end_first_step()      # dead parameters lose their bucket views before the capture (ADVICE)
+                if self.capture_exchange:         # warm RCCL's kernels / buffers for these bucket sizes outside the capture
+                    self.reducer.exchange()
                 if self.capture_optimizer:        # warm the optimizer's kernels (and allocate its state) outside the capture
                     self._clip()
                     self.optimizer.step()
@@ -183,6 +190,8 @@ class TrainStep:
         try:
             with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
                 self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
+                if self.capture_exchange:
+                    self.reducer.exchange()       # buckets not launched by a hook yet, the joins, the widening copies
                 if self.capture_optimizer:
                     self._clip()
                     self.optimizer.step()
@@ -280,7 +289,7 @@ class TrainStep:
             if not (got == got and abs(got - expect) <= 0.2 * abs(expect) + 1e-3):
                 self.drop_graph()
                 raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
-        if self.reducer.active:
+        if self.reducer.active and not self.capture_exchange:
             self.reducer.exchange()          # the same path as the eager step's finish(): wire compression included
         if not self.capture_optimizer:
             self._clip()
