@@ -45,6 +45,8 @@ __device__ __forceinline__ void split_range(int tiles, int n_split, int split, i
   t1 = min(t0 + chunk, tiles);
 }
 
+constexpr float kDefer = 8.f;               // log2 units: see roi_attn_fwd
+
 #define TRANSOAR_ATTN_KERNEL __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 // ---------------------------------------------------------------------------
@@ -130,8 +132,12 @@ TRANSOAR_ATTN_KERNEL void roi_attn_fwd(
     }
     mt = fmaxf(mt, other_half(mt));
     const float m_new = fmaxf(m_run, mt);
-    if (__any(m_new > m_run)) {
-      // the running maximum of some row grew: rescale the accumulator.  Through explicit accumulator-register moves:
+    // Deferred rescaling: the accumulator follows the running maximum only when some row's maximum has grown by more than
+    // 2^kDefer since its last rescale; until then P = exp2(S - m_run) may reach 2^kDefer (harmless in fp32 / bf16, and the
+    // final division by the row sum undoes it).  Rescaling on every growth ran on most tiles (a wave holds 32 rows: one of
+    // them sees a new maximum almost every tile) and cost 576 VALU instructions each time -- 10 per MFMA over the kernel.
+    if (__any(m_new > m_run + kDefer)) {
+      // rescale the accumulator.  Through explicit accumulator-register moves:
       // written as plain fp32 multiplies, the 192 accumulator values are allocated as arch VGPRs next to the 200 of
       // the softmax / fragment code, and hipcc spills 84 registers around the tile loop.
       const float alpha = m_new == -INFINITY ? 1.f : fast_exp2(m_run - m_new);     // m_run = -inf: exp2(-inf) = 0, acc is 0
@@ -139,10 +145,12 @@ TRANSOAR_ATTN_KERNEL void roi_attn_fwd(
       for (int ct = 0; ct < kCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float x;
-          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[ct][r]));
-          x *= alpha;
-          asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[ct][r]) : "v"(x));
+          // in place ("+a"): as separate read / write statements each element became a NEW value inside the branch, and
+          // hipcc resolved the join behind it by copying all 192 accumulator registers through VGPRs on EVERY trip
+          // (416 v_accvgpr moves per tile: the kernel was VALU-bound at 10 VALU instructions per MFMA)
+          float tmp;
+          asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                       : "+a"(acc[ct][r]), "=&v"(tmp) : "v"(alpha));
         }
       l_run *= alpha;
       m_run = m_new;

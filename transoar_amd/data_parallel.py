@@ -14,8 +14,13 @@ Mechanics, chosen for xGMI (7 point-to-point links per GPU: a few large
 messages, launched early):
   * parameters are packed, in reverse registration order (~ the order autograd
     finishes them: heads -> neck -> FPN decoder -> encoder stage 5 ... 0), into
-    a few flat fp32 buckets (default 48 MiB; the model has ~217 MB of grads);
-    ``param.grad`` are views into the buckets, so there is no pack/unpack copy;
+    a few flat fp32 buckets (default 48 MiB; the model has ~217 MB of grads).
+    Autograd hands every parameter a FRESH gradient tensor; when the last gradient
+    of a bucket has landed, ONE multi-tensor copy packs the bucket and the
+    parameters' ``.grad`` become views of it (what the optimizer then reads).
+    (Round 3 made the views the ``.grad`` up front: autograd then accumulates into
+    them with one read-modify-write kernel per parameter -- ~170 launches and a
+    217-MB zero fill per step, most of the 0.9 ms a one-rank group cost);
   * a post-accumulate-grad hook counts a bucket's parameters down and launches
     its all-reduce asynchronously the moment the last one lands, so the
     exchange of the big early buckets (encoder stage 5: 96 MB) hides behind the
@@ -88,9 +93,8 @@ class GradientAllReducer:
 
     def _add_bucket(self, params):
         b = _Bucket(list(params), params[0].device, params[0].dtype, self.wire_dtype if self.active else None)
-        for p, v in zip(b.params, b.views):
+        for p in b.params:
             self._bucket_of[p] = b
-            p.grad = v
         self.buckets.append(b)
 
     # ---- per step -----------------------------------------------------------
@@ -101,29 +105,38 @@ class GradientAllReducer:
         return counts
 
     def begin(self):
-        """Call before forward/backward: zero the gradient buckets."""
+        """Call before forward/backward: drop the old gradients (autograd allocates fresh ones; a bucket is packed when
+        its last gradient has landed)."""
+        for p in self.params:
+            p.grad = None
         if not self.flat:
-            for p in self.params:
-                p.grad = None
             return
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = b.expected
             b.handle = None
-            for p, v in zip(b.params, b.views):     # someone may have replaced .grad
-                if p in self._dead:
-                    continue
-                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                    p.grad = v
         self._fired.clear()
+
+    def _pack(self, b):
+        """The bucket's fresh gradients -> its flat buffer in one multi-tensor copy; .grad becomes the view."""
+        live = [(p, v) for p, v in zip(b.params, b.views) if p.grad is not None]
+        if live:
+            torch._foreach_copy_([v for _, v in live], [p.grad for p, _ in live])
+            for p, v in live:
+                p.grad = v
+        if self._first_step:                      # parameters without a gradient: zero slices (they are dropped after this step)
+            for p, v in zip(b.params, b.views):
+                if p.grad is None:
+                    v.zero_()
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
         if self._first_step:
             self._fired.add(p)
         b.pending -= 1
-        if b.pending == 0 and self.overlap and self.active:
-            b.handle = self._launch(b)
+        if b.pending == 0:
+            self._pack(b)
+            if self.overlap and self.active:
+                b.handle = self._launch(b)
 
     def _launch(self, b):
         if b.wire is not None:
@@ -147,6 +160,9 @@ class GradientAllReducer:
         (the tail of the eager step, and the whole exchange of the captured step, which has no hooks running)."""
         for b in self.buckets:
             if b.handle is None:     # eager: first step only (a parameter without gradient held the bucket back)
+                if b.pending > 0:
+                    self._pack(b)
+                    b.pending = 0
                 b.handle = self._launch(b)
         for b in self.buckets:
             b.handle.wait()
@@ -159,6 +175,9 @@ class GradientAllReducer:
             return
         for b in self.buckets:
             b.expected = sum(1 for p in b.params if p in self._fired)
+            if b.pending > 0:                      # (one rank, no exchange: a bucket held back by a dead parameter)
+                self._pack(b)
+                b.pending = 0
             for p in b.params:
                 if p not in self._fired:          # dead parameter: no gradient, the optimizer skips it
                     self._dead.add(p)

@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
 ABI_VERSION = 2
 STREAM_SQUARE = os.environ.get("TRANSOAR_GEMM_STREAM_SQUARE", "0") == "1"
+STREAM_N384 = os.environ.get("TRANSOAR_GEMM_N384", "0") == "1"
 STREAM = os.environ.get("TRANSOAR_GEMM_STREAM", "1") != "0"      # the K = 384 / N = 384 streaming kernels (csrc/gemm_stream.hip)
 _DT = {torch.float32: 0, torch.bfloat16: 2, torch.float16: 3}
 
@@ -57,8 +58,8 @@ def stream_kind(x, w, out_dtype=None, relu=False):
         return None
     if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE):
         return "k384"            # (384 x 384: the tiled kernel measures 0.149 ms against 0.158, profiles/r04_gemm_bench.jsonl)
-    if n == 384 and k % 32 == 0 and k != 384 and (m + 128) * k * 2 < 0xffffffff:
-        return "n384"
+    if STREAM_N384 and n == 384 and k % 32 == 0 and k != 384 and (m + 128) * k * 2 < 0xffffffff:
+        return "n384"            # (off by default: 0.315 ms on 234 000 x 1024 -> 384 against the tiled kernel's 0.269)
     return None
 
 
