@@ -103,6 +103,20 @@ int transoar_sampling_head_forward(const void* proj, const float* ref, long ref_
 int transoar_sampling_head_backward(const float* g_loc, const float* g_attn, const float* attn, const long* shapes,
                                     void* g_proj, long tokens, int M, int L, int P, void* hip_stream);
 
+/*
+ * LayerNorm over short rows (cols a multiple of 8, 8 <= cols <= 512): the norms of the Swin encoder stages
+ * (transoar/models/backbones/encoder_blocks.py:143-327, nn.LayerNorm over 48 .. 384 channels of 10^5 .. 10^6 tokens).
+ *   forward:  y16 (rows, cols) bf16 = LayerNorm(x) * weight + bias, x bf16 or fp32; mean / rstd (rows) fp32 are kept for
+ *             the backward
+ *   backward: dx (x's type) from g16 (bf16); partials (transoar_ln_rows_partial_rows(), 2 * cols) fp32: every row holds a
+ *             partial sum of [weight gradient | bias gradient] (column-sum them, e.g. transoar_rows_colsum_small)
+ */
+int transoar_ln_rows_forward(const void* x, int x_is_bf16, const float* weight, const float* bias, float eps, void* y16,
+                             float* mean, float* rstd, long rows, int cols, void* hip_stream);
+int transoar_ln_rows_backward(const void* g16, const void* x, int x_is_bf16, const float* weight, const float* mean,
+                              const float* rstd, void* dx, float* partials, long rows, int cols, void* hip_stream);
+int transoar_ln_rows_partial_rows(void);
+
 int transoar_tokens_abi_version(void);
 
 #ifdef __cplusplus

@@ -129,7 +129,7 @@ def test_sampling_head_and_colsum_argument_errors():
     qb = tok.transoar_pos_query_backward
     qb.argtypes = [p, p, i, lg, p, lg, i, p]
     assert qb(p16, p16, 4, 8, None, 16, 384, None) == -1
-    assert tok.transoar_pos_query_partial_rows() > 0 and tok.transoar_tokens_abi_version() == 5
+    assert tok.transoar_pos_query_partial_rows() > 0 and tok.transoar_tokens_abi_version() == 6
     c = rows.transoar_rows_colsum
     c.argtypes = [p, p, p, lg, i, p]
     assert c(None, p16, p16, 8, 8, None) == -1

@@ -241,3 +241,32 @@ def test_pos_query_matches_the_eager_chain(cols):
     assert q.dtype == torch.bfloat16 and torch.equal(q, q_ref)
     assert torch.equal(gx, gx_ref)
     assert (gle - gle_ref).abs().max().item() <= 1e-4 * gle_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cols", [48, 96, 192, 384, 512, 8])
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float32])
+def test_layernorm_rows_matches_torch(cols, xdt):
+    """Short-row LayerNorm (Swin stages: 48 .. 384 channels) against F.layer_norm in fp32: output, input gradient and the
+    weight / bias gradients (per-wave partial sums + one column-sum)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd import tokens
+    g = torch.Generator(device="cuda").manual_seed(cols)
+    n_rows = 70001
+    x = (torch.randn(n_rows, cols, device="cuda", generator=g) * 2 + 0.5).to(xdt).requires_grad_()
+    norm = torch.nn.LayerNorm(cols).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * torch.randn(cols, device="cuda", generator=g))
+        norm.bias.copy_(0.2 * torch.randn(cols, device="cuda", generator=g))
+    assert tokens.layernorm_rows_usable(x, norm)
+    y = tokens.layernorm_rows(x, norm)
+    gy = torch.randn(n_rows, cols, device="cuda", generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_()
+    wr, br = norm.weight.detach().clone().requires_grad_(), norm.bias.detach().clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (cols,), wr, br, norm.eps)
+    yr.backward(gy.float())
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-30)
+    assert y.dtype == torch.bfloat16 and rel(y, yr) <= 2.0 ** -8
+    assert x.grad.dtype == xdt and rel(x.grad, xr.grad) <= (2.0 ** -7 if xdt == torch.bfloat16 else 1e-4)
+    assert rel(norm.weight.grad, wr.grad) <= 1e-3 and rel(norm.bias.grad, br.grad) <= 1e-3

@@ -7,6 +7,8 @@
 // registers (mean, then centred second moment), fp32.  HBM-bound by design:
 // forward moves 18 B/element (fp32 stream) where the unfused chain moves 48.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "../../include/transoar_tokens.h"
@@ -545,6 +547,140 @@ __global__ __launch_bounds__(256) void sampling_head_bwd_p16(const float* __rest
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------
+// LayerNorm over SHORT rows (48 .. 512 channels, a multiple of 8): the norm1 / norm2 / patch-merge norms of the Swin
+// encoder stages (transoar/models/backbones/encoder_blocks.py:143-327, nn.LayerNorm over 48 / 96 / 192 / 384 channels
+// of 10^5 .. 10^6 tokens).  aten's kernels take 0.4 ms per pass on the 1.6 M x 48 fp32 rows of stage 2 (23 ms per step);
+// add_ln_* above needs a multiple of 128 columns.  Here a GROUP of G lanes (the next power of two >= cols / 8) owns a row,
+// 8 channels per lane in registers, statistics by xor-shuffles inside the group; output bf16 (what the following
+// projection rounds to under autocast).  Backward: dx in the input's type, and per-lane partial sums of the weight /
+// bias gradients over a grid-stride loop of rows -> partials (n_partial_rows, 2 * cols) for one column-sum launch.
+// ---------------------------------------------------------------------------
+constexpr int kLnBlocks = 1024;          // persistent workgroups of the backward (4 waves each)
+
+template <bool XBF>
+__device__ __forceinline__ void ln_load8(const void* x, long row, int cols, int c0, float (&v)[8]) {
+  if (XBF) {
+    const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(x) + row * cols + c0);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_lo(w[i]); v[2 * i + 1] = bf16_hi(w[i]); }
+  } else {
+    const float4* pf = reinterpret_cast<const float4*>(static_cast<const float*>(x) + row * cols + c0);
+    const float4 a = pf[0], b = pf[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <int G, bool XBF>
+__global__ __launch_bounds__(256) void ln_rows_fwd(const void* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
+                                                   float eps, uint4* __restrict__ y16, float* __restrict__ mean_out,
+                                                   float* __restrict__ rstd_out, long rows, int cols) {
+  constexpr int RPW = 64 / G;                                     // rows per wave
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  const long row = (static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const int c0 = gl * 8;
+  const bool on = row < rows && c0 < cols;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (on) ln_load8<XBF>(x, row, cols, c0, v);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  const float mean = group_sum<G>(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float d = on ? v[i] - mean : 0.f; q += d * d; }
+  const float rstd = rsqrtf(group_sum<G>(q) / cols + eps);
+  if (!on) return;
+  const float4 w0 = *reinterpret_cast<const float4*>(weight + c0), w1 = *reinterpret_cast<const float4*>(weight + c0 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+  const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * ww[i] + bb[i];
+  y16[(row * cols + c0) >> 3] = uint4{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+  if (gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <int G, bool XBF>
+__global__ __launch_bounds__(256) void ln_rows_bwd(const uint4* __restrict__ g16, const void* __restrict__ x, const float* __restrict__ weight,
+                                                   const float* __restrict__ mean_in, const float* __restrict__ rstd_in, void* __restrict__ dx,
+                                                   float* __restrict__ partials, long rows, int cols) {
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  const int c0 = gl * 8;
+  const bool col_on = c0 < cols;
+  float ww[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col_on) {
+    const float4 w0 = *reinterpret_cast<const float4*>(weight + c0), w1 = *reinterpret_cast<const float4*>(weight + c0 + 4);
+    ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+  }
+  float dw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, db[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long wave_id = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long n_waves = static_cast<long>(gridDim.x) * 4;
+  for (long r0 = wave_id * RPW; r0 < rows; r0 += n_waves * RPW) {
+    const long row = r0 + sub;
+    const bool on = row < rows && col_on;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mean = 0.f, rstd = 0.f;
+    if (on) {
+      ln_load8<XBF>(x, row, cols, c0, v);
+      const uint4 q = g16[(row * cols + c0) >> 3];
+      const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { g[2 * i] = bf16_lo(w4[i]); g[2 * i + 1] = bf16_hi(w4[i]); }
+      mean = mean_in[row];
+      rstd = rstd_in[row];
+    }
+    float xh[8], gw[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xh[i] = (v[i] - mean) * rstd;
+      gw[i] = g[i] * ww[i];
+      s1 += gw[i];
+      s2 += gw[i] * xh[i];
+      dw[i] += g[i] * xh[i];
+      db[i] += g[i];
+    }
+    const float c1 = group_sum<G>(s1) / cols, c2 = group_sum<G>(s2) / cols;
+    if (on) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rstd * (gw[i] - c1 - xh[i] * c2);
+      if (XBF) {
+        reinterpret_cast<uint4*>(dx)[(row * cols + c0) >> 3] =
+            uint4{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+      } else {
+        float4* po = reinterpret_cast<float4*>(static_cast<float*>(dx) + row * cols + c0);
+        po[0] = float4{o[0], o[1], o[2], o[3]};
+        po[1] = float4{o[4], o[5], o[6], o[7]};
+      }
+    }
+  }
+  // the RPW row groups of a wave hold partial sums of the same columns: add them, then one partial row per wave
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int d = G; d < 64; d <<= 1) { dw[i] += __shfl_xor(dw[i], d, 64); db[i] += __shfl_xor(db[i], d, 64); }
+  }
+  if (sub == 0 && col_on) {
+    float* pr = partials + wave_id * (2L * cols);
+    *reinterpret_cast<float4*>(pr + c0) = float4{dw[0], dw[1], dw[2], dw[3]};
+    *reinterpret_cast<float4*>(pr + c0 + 4) = float4{dw[4], dw[5], dw[6], dw[7]};
+    *reinterpret_cast<float4*>(pr + cols + c0) = float4{db[0], db[1], db[2], db[3]};
+    *reinterpret_cast<float4*>(pr + cols + c0 + 4) = float4{db[4], db[5], db[6], db[7]};
+  }
+}
+
 static unsigned keep_threshold(float keep_prob) {
   const float t = keep_prob * 65536.0f + 0.5f;
   return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : static_cast<unsigned>(t));
@@ -707,7 +843,52 @@ extern "C" int transoar_pos_query_backward(const void* gq16, const int* level_st
   return static_cast<int>(hipGetLastError());
 }
 
+
+static int ln_group(int cols) {
+  const int lanes = cols / 8;
+  int g = 1;
+  while (g < lanes) g <<= 1;
+  return g;
+}
+#define LN_DISPATCH(G_, BODY)                       \
+  switch (G_) {                                     \
+    case 8: { constexpr int G = 8; BODY; } break;   \
+    case 16: { constexpr int G = 16; BODY; } break; \
+    case 32: { constexpr int G = 32; BODY; } break; \
+    default: { constexpr int G = 64; BODY; } break; \
+  }
+
+extern "C" int transoar_ln_rows_forward(const void* x, int x_is_bf16, const float* weight, const float* bias, float eps, void* y16,
+                                        float* mean, float* rstd, long rows, int cols, void* hip_stream) {
+  if (!x || !weight || !bias || !y16 || !mean || !rstd) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols < 8 || cols > 512 || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int g = std::max(8, ln_group(cols));
+  const long rows_per_block = 4L * (64 / g);
+  const dim3 grid(static_cast<unsigned>((rows + rows_per_block - 1) / rows_per_block));
+  LN_DISPATCH(g, {
+    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_fwd<G, true>), grid, dim3(256), 0, st, x, weight, bias, eps, static_cast<uint4*>(y16), mean, rstd, rows, cols);
+    else hipLaunchKernelGGL((ln_rows_fwd<G, false>), grid, dim3(256), 0, st, x, weight, bias, eps, static_cast<uint4*>(y16), mean, rstd, rows, cols);
+  });
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_ln_rows_partial_rows(void) { return kLnBlocks * 4; }
+
+extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_is_bf16, const float* weight, const float* mean,
+                                         const float* rstd, void* dx, float* partials, long rows, int cols, void* hip_stream) {
+  if (!g16 || !x || !weight || !mean || !rstd || !dx || !partials) return TRANSOAR_TOK_ERR_NULL;
+  if (rows <= 0 || cols < 8 || cols > 512 || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int g = std::max(8, ln_group(cols));
+  LN_DISPATCH(g, {
+    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_bwd<G, true>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx, partials, rows, cols);
+    else hipLaunchKernelGGL((ln_rows_bwd<G, false>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx, partials, rows, cols);
+  });
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_pos_query_partial_rows(void) { return kPersistentWaves / kWaves; }
 
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 5; }
+extern "C" int transoar_tokens_abi_version(void) { return 6; }

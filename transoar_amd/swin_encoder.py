@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import rows, win_attn
+from . import tokens as fused_tokens
 from .token_linear import token_linear
 
 MIN_TOKENS = 8192            # token matrices at least this tall take the hand-written GEMMs (token_linear)
@@ -35,6 +36,13 @@ def _fast(x):
     """The hand-written path of a Swin block: bf16 autocast on the GPU (fp32 / CPU: the plain torch formulation, which the
     golden parity tests pin)."""
     return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+
+
+def _norm16(x, norm):
+    """LayerNorm rounded to bf16: the short-row kernel (tokens.layernorm_rows: 48 .. 512 channels) or torch + a cast."""
+    if fused_tokens.layernorm_rows_usable(x, norm):
+        return fused_tokens.layernorm_rows(x, norm)
+    return norm(x).to(torch.bfloat16)
 
 
 class _Rows(torch.autograd.Function):
@@ -210,15 +218,16 @@ class SwinBlock(nn.Module):
         b, n_tok, c = x.shape
         win, shift = effective_window(grid, self.window_size, self.shift_size)
         lay = window_layout(grid, win, shift, x.device)
-        y = self.norm1(x)
         if _fast(x) and (c * 2) % 16 == 0:
             # bf16 tokens (what the qkv projection rounds them to anyway) through the row kernels both ways
-            y = torch.cat((y.to(torch.bfloat16), y.new_zeros((b, 1, c), dtype=torch.bfloat16)), dim=1)     # row n_tok: the padding token
+            y = _norm16(x, self.norm1)
+            y = torch.cat((y, y.new_zeros((b, 1, c))), dim=1)                                                  # row n_tok: the padding token
             y = _Rows.apply(y, lay.gather32, lay.gather_back).view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
             y = self.attn(y, lay.mask, lay.mask_bits)
             y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, lay.scatter_back)                # merge + shift back + crop
             x = x + self.drop_path(y)
-            return x + self.drop_path(self.mlp(self.norm2(x).to(torch.bfloat16)))
+            return x + self.drop_path(self.mlp(_norm16(x, self.norm2)))
+        y = self.norm1(x)
         y = torch.cat((y, y.new_zeros(b, 1, c)), dim=1)                      # row n_tok: the padding token
         y = y[:, lay.gather].view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
         y = self.attn(y, lay.mask)
@@ -246,10 +255,9 @@ class PatchMerging(nn.Module):
         x = x[:, : d - d % 2]                                   # stride-2 slicing of the reference drops a last odd plane
         x = x.view(b, d // 2, 2, h // 2, 2, w // 2, 2, c)       # (b, D, dd, H, dh, W, dw, c)
         x = x.permute(0, 1, 3, 5, 2, 6, 4, 7).reshape(b, d // 2, h // 2, w // 2, 8 * c)     # blocks ordered (dd, dw, dh)
-        y = self.norm(x)
-        if _fast(y):
-            return token_linear(y.to(torch.bfloat16), self.reduction.weight, None, force_hip=True, min_tokens=MIN_TOKENS)
-        return self.reduction(y)
+        if _fast(x):
+            return token_linear(_norm16(x.contiguous(), self.norm), self.reduction.weight, None, force_hip=True, min_tokens=MIN_TOKENS)
+        return self.reduction(self.norm(x))
 
 
 class ConvPatchMerging(nn.Module):
