@@ -538,7 +538,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         const long waves = static_cast<long>(d.N) * d.M * cl.chunks_per_slab;
         if (mma) {
           if constexpr (sizeof(VT) == 2)       // 16 sorted points per MFMA K-step (msda3d_cells_mma.hpp)
-            hipLaunchKernelGGL((msda3d_bwd_value_cells_mma<VT>), dim3(static_cast<unsigned>((((waves + 3) / 4 + 7) / 8) * 8)), dim3(256), 0,
+            hipLaunchKernelGGL((msda3d_bwd_value_cells_mma<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0,
                                cst, go, count, recs4, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
                                cl_d, r_order_d);
         } else {
@@ -553,7 +553,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         const long n_wg = static_cast<long>(d.N) * fine_bricks * d.M;
         if (mma) {
           if constexpr (sizeof(VT) == 2)
-            hipLaunchKernelGGL((msda3d_bwd_value_tile_mma<VT>), dim3(static_cast<unsigned>(((n_wg + 7) / 8) * 8)), dim3(kBrickThreads), 0, st,
+            hipLaunchKernelGGL((msda3d_bwd_value_tile_mma<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st,
                                go, count, recs4, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
                                d.S, d.M, fine_bricks, n_wg, r_order_d);
         } else {

@@ -136,13 +136,9 @@ __global__ __launch_bounds__(256, 4) void msda3d_bwd_value_cells_mma(
   __shared__ __attribute__((aligned(16))) float lds_recs[4][16 * 8];
 
   const int lane = threadIdx.x & 63, wave_in_wg = uniform(threadIdx.x >> 6);
-  // XCD-contiguous chunk order (block b runs on XCD b % 8): the chunks an XCD has in flight are neighbours in the sorted
-  // list, i.e. neighbouring cells, whose points come from the same queries -- their grad_out rows (each needed by the 4
-  // points of its query on this level) are then fetched into ONE L2 instead of up to eight (round 3: 10 % L2 hits, 1.7 GB
-  // fetched for 2.2 GB of gathered rows)
-  const long lb = xcd_contiguous_block(blockIdx.x, (static_cast<long>(n_slabs) * cl.chunks_per_slab + 3) / 4);      // the grid is rounded up to a multiple of 8
-  if (lb < 0) return;
-  const int wid = uniform(static_cast<int>(lb) * 4 + wave_in_wg);
+  // (an XCD-contiguous chunk order -- neighbouring cells, whose points share grad_out rows, on ONE L2 -- measured
+  // SLOWER: 0.39 -> 0.43 ms; neighbouring chunks also flush into the same scratch rows, and their atomics then collide)
+  const int wid = uniform(static_cast<int>(blockIdx.x) * 4 + wave_in_wg);
   const int slab = wid / cl.chunks_per_slab, chunk = wid - slab * cl.chunks_per_slab;
   if (slab >= n_slabs) return;
   const int* off = offset + static_cast<long>(slab) * cells_per_slab;
@@ -234,9 +230,9 @@ __global__ __launch_bounds__(kBrickThreads) void msda3d_bwd_value_tile_mma(
   __shared__ __attribute__((aligned(16))) unsigned char lds_rows[NW][16 * kCmRowPitch];
   __shared__ __attribute__((aligned(16))) float lds_recs[NW][16 * 8];
 
-  // XCD-contiguous brick order: neighbouring bricks (their 5 x 5 x 9 cell boxes overlap: a point is fetched 1.76 x) share an L2
-  const long wg = xcd_contiguous_block(blockIdx.x, n_wg);
-  if (wg < 0) return;
+  // (XCD-contiguous brick order measured 3 % slower: 0.571 -> 0.588 ms)
+  const long wg = blockIdx.x;
+  if (wg >= n_wg) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int m = static_cast<int>(wg % M);
   const long t1 = wg / M;

@@ -27,6 +27,7 @@ from . import conv_gemm, gemm, rows, shadow
 
 MIN_TOKENS = 32768          # below this the stock path is as fast
 LAST_PATH = None            # "hip-gemm" / "blas": which forward ran last (tests)
+OWN_FFN2 = os.environ.get("TRANSOAR_OWN_FFN2", "1") != "0"
 USE_HIP_GEMM = {"1": True, "0": False}.get(os.environ.get("TRANSOAR_HIP_GEMM", ""), None)     # None: per shape
 
 
@@ -38,7 +39,10 @@ def _hip_gemm(x2, w, force=False):
         return USE_HIP_GEMM
     # K = N = 384 on the tiled kernel (round 2); every K = 384 or N = 384 product of >= 16 384 tokens on the streaming
     # kernels of csrc/gemm_stream.hip (round 4: the FFN shapes 384 -> 1024 -> 384 and their data gradients included)
-    return force or (x2.shape[1] == 384 and w.shape[0] == 384) or gemm.stream_kind(x2, w) is not None
+    # ... and 1024 -> 384 (linear2 and linear1's data gradient) on the tiled kernel as well: 0.27 ms against hipBLASLt's
+    # 0.22, the price (0.1 ms per step) of a refinement block without a library GEMM
+    return (force or (x2.shape[1] == 384 and w.shape[0] == 384) or gemm.stream_kind(x2, w) is not None
+            or (OWN_FFN2 and w.shape[0] == 384 and x2.shape[0] >= 16384))
 
 
 def _chunks(tokens, n_out, n_in):
