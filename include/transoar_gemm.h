@@ -43,6 +43,16 @@ int transoar_gemm_n384(const void* A, const void* B, const float* bias, void* C,
 int transoar_gemm_k384_drop(const void* A, const void* B, const float* bias, void* C, int M, int N, int relu,
                             const int* drop_seed, float keep_prob, float keep_scale, void* hip_stream);
 
+/* Weight gradient of a token linear layer with 384 channels on one side (reference: the autograd of nn.Linear in
+ * ops/modules/ms_deform_attn.py:109-140 and backbones/decoder_blocks.py:157-174), fp32 out:
+ *   out = A^T B,  A (T, Na) bf16, B (T, 384) bf16, Na a multiple of 128;
+ *   transpose_out == 0: out (Na, 384) row-major;  != 0: out (384, Na) row-major (the case "384 is the layer's OUTPUT width").
+ * The tokens are split into `chunks` = transoar_gemm_wgrad384_chunks(T, Na) ranges, one workgroup per range and column
+ * tile; `part` holds chunks * Na * 384 floats of partial sums (device scratch), summed into `out` by a second kernel. */
+int transoar_gemm_wgrad384_chunks(int T, int Na);
+int transoar_gemm_wgrad384(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
+                           int chunks, void* hip_stream);
+
 int transoar_gemm_abi_version(void);
 
 #ifdef __cplusplus

@@ -131,3 +131,25 @@ def test_streaming_k384_square_and_fused_relu_dropout():
     assert rel(yy, yr) <= 2.0 ** -7
     assert rel(xg.grad, xr.grad) <= 3e-2          # K = 1024 products of the bf16-rounded hidden gradient (observed 0.021)
     assert rel(lin.weight.grad, wr.grad) <= 3e-3
+
+
+@pytest.mark.parametrize("t,n,k", [(20000, 384, 384), (33001, 1024, 384), (33001, 384, 1024), (16384, 512, 384), (17000, 384, 128),
+                                   (70001, 128, 384)])
+def test_wgrad384_matches_fp32(t, n, k):
+    """dW = gy^T x over the tokens on the token-streaming kernel (csrc/gemm_stream.hip, wgrad384_kernel): both output
+    orientations, both column-tile widths, token counts that are not a multiple of the 32-token stage."""
+    from transoar_amd import token_linear
+    g = torch.Generator(device="cuda").manual_seed(t + n)
+    gy = torch.randn(t, n, device="cuda", generator=g).bfloat16()
+    x = torch.randn(t, k, device="cuda", generator=g).bfloat16()
+    assert gemm.wgrad384_usable(gy, x)
+    dw = token_linear.weight_grad(gy, x)
+    assert dw.dtype == torch.float32 and dw.shape == (n, k)
+    ref = gy.float().t() @ x.float()
+    # bf16 products are exact in fp32; only the summation order differs
+    assert (dw - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # and the round-3 path (one-tap conv GEMM) agrees
+    from transoar_amd import conv_gemm
+    old = conv_gemm.linear_wgrad(x, gy)
+    assert (dw - old).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert torch.equal(dw, token_linear.weight_grad(gy, x))          # deterministic: fixed chunking, no atomics

@@ -46,10 +46,12 @@ from transoar_amd import conv_gemm, token_linear  # noqa: E402
 for m, k, n in ((234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (234000, 384, 576), (204800, 96, 96), (204800, 384, 3072)):
     x = torch.randn(m, k, device="cuda").bfloat16()
     gy = torch.randn(m, n, device="cuda").bfloat16()
-    ours = time_ms(lambda: conv_gemm.linear_wgrad(x, gy))
+    ours = time_ms(lambda: token_linear.weight_grad(gy, x))          # round 4: wgrad384 where it applies
+    voxel = time_ms(lambda: conv_gemm.linear_wgrad(x, gy))           # round 3: the one-tap case of the voxel-major conv GEMM
     token_linear.USE_HIP_WGRAD = False
     blas = time_ms(lambda: token_linear.weight_grad(gy, x))
     token_linear.USE_HIP_WGRAD = True
     fl = 2.0 * m * k * n
-    print(json.dumps({"wgrad": True, "T": m, "K": k, "N": n, "ours_ms": round(ours, 4), "hipblaslt_chunked_ms": round(blas, 4),
+    print(json.dumps({"wgrad": True, "T": m, "K": k, "N": n, "kernel": "wgrad384" if gemm.wgrad384_usable(gy, x) else "conv_gemm",
+                      "ours_ms": round(ours, 4), "conv_gemm_ms": round(voxel, 4), "hipblaslt_chunked_ms": round(blas, 4),
                       "ours_TFs": round(fl / ours / 1e9, 1), "frac_of_2.5PF": round(fl / ours / 1e9 / 2500, 3)}), flush=True)

@@ -341,4 +341,4 @@ extern "C" int transoar_gemm_nt(const void* A, const void* B, const float* bias,
              : launch<false, false>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st);
 }
 
-extern "C" int transoar_gemm_abi_version(void) { return 2; }
+extern "C" int transoar_gemm_abi_version(void) { return 3; }

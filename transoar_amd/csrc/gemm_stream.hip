@@ -247,6 +247,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------
+// weight gradient with 384 columns on one side: Out = A^T B over the token axis
+// ---------------------------------------------------------------------------
+// A (T, Na) and B (T, 384) bf16, tokens outermost (the layer's input and the gradient of its output, or the other way
+// round).  A workgroup owns 32 NT columns of A (NT = 4 or 8) x all 384 columns of B for one chunk of tokens; wave w
+// holds the accumulators of B's columns [96 w, 96 w + 96): NT x 3 MFMA tiles (96 / 192 fp32 registers).  Tokens stream
+// through LDS in stages of 32 (the B tile in the 32 x 768-byte layout of mfma_stream.hpp, the A tile as [32 tokens]
+// [64 NT bytes], its 64-byte windows XORed with (token & 3) so that the transposing reads of four token rows hit
+// distinct banks), four-stage ring, two stages ahead, one bare barrier per stage.  Both operands of an MFMA come from
+// transposing reads (channel = lane & 31, eight tokens per lane): NT + 3 fragments feed 3 NT MFMAs per 16 tokens.
+// Each workgroup writes its fp32 partial (its chunk of tokens); wgrad384_reduce sums the chunks.
+// Block order: the NT-tiles of one token chunk sit on the same XCD (block % 8) next to each other, so the chunk's
+// B tiles come from that XCD's L2 for all but the first of them.
+constexpr int kWgRing = 4;
+template <int NT> struct WgTile {
+  static constexpr int kPitch = 64 * NT;                // bytes per token row of the A tile
+  static constexpr int kABytes = 32 * kPitch;
+  static constexpr int kStage = kTile + kABytes;        // 32 / 40 KiB
+  static constexpr int kPerWave = kABytes / 4096;       // 1-KiB DMA pieces of the A tile per wave
+  static constexpr int kIssue = 6 + kPerWave;           // DMA instructions per stage and wave
+};
+
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned soff_in, int voff, unsigned char* lds_piece) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_piece)));
+  const unsigned soff = __builtin_amdgcn_readfirstlane(soff_in);
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+      : "memory");
+}
+__device__ __forceinline__ s16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int NT, bool TR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad384_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ part,
+    int T, int Na, int chunk_len, int n_chunks, int n_tiles) {
+  using W = WgTile<NT>;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kWgRing * W::kStage];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
+  const int tile = by % n_tiles, chunk = (by / n_tiles) * 8 + bx;
+  if (chunk >= n_chunks) return;
+  const int n0 = tile * 32 * NT;
+  const int t0 = chunk * chunk_len;
+  const int t_end = min(T, t0 + chunk_len);
+  const int n_stages = (t_end - t0 + 31) >> 5;
+  const unsigned lda_bytes = static_cast<unsigned>(Na) * 2u;
+  // the descriptors end at the chunk's last token: the rows of the last stage past it read as zeros
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, static_cast<int>(static_cast<unsigned>(t_end) * lda_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, static_cast<int>(static_cast<unsigned>(t_end) * static_cast<unsigned>(kRowBytes)), 0x00020000);
+  const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
+
+  // DMA source offsets of this wave's pieces of the A tile (lane-linear LDS image, windows swizzled at the source)
+  int avoff[W::kPerWave];
+#pragma unroll
+  for (int j = 0; j < W::kPerWave; ++j) {
+    const int o = (W::kPerWave * wave + j) * 1024 + 16 * lane;
+    const int row = o / W::kPitch, q = (o % W::kPitch) >> 4;
+    avoff[j] = row * static_cast<int>(lda_bytes) + ((q ^ ((row & 3) << 2)) << 4);
+  }
+  // fragment bases (mfma_stream.hpp, FragBase::cols, for this wave's three channel tiles of B; the same scheme on the A tile)
+  int abase[4], bbase[3][2];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) abase[b] = kTile + (8 * kh + r) * W::kPitch + 64 * (b ^ r) + 32 * g + 8 * c;
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int ct = 3 * wave + jj;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      bbase[jj][i] = (8 * kh + r + 4 * i) * kRowBytes + 64 * ((ct & 3) ^ r) + 16 * ((2 * g + (c >> 1)) ^ (2 * kh + i)) + 8 * (c & 1) + 256 * (ct >> 2);
+  }
+  f32x16 acc[NT][3];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+  const unsigned a_soff0 = static_cast<unsigned>(t0) * lda_bytes + static_cast<unsigned>(n0) * 2u;
+  auto issue = [&](int s) {
+    unsigned char* stg = lds + (s % kWgRing) * W::kStage;
+    dma_tile(brs, static_cast<unsigned>(t0 + 32 * s) * static_cast<unsigned>(kRowBytes), stg, wave, lane);
+#pragma unroll
+    for (int j = 0; j < W::kPerWave; ++j)
+      dma_piece(ars, a_soff0 + static_cast<unsigned>(32 * s) * lda_bytes, avoff[j], stg + kTile + (W::kPerWave * wave + j) * 1024);
+  };
+  issue(0);
+  if (n_stages > 1) issue(1);
+  for (int s = 0; s < n_stages; ++s) {
+    if (s + 2 < n_stages) {
+      issue(s + 2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W::kIssue) : "memory");
+    } else if (s + 1 < n_stages) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::kIssue) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // one barrier per stage: the stage read here is overwritten by stage s + 4, issued at the top of iteration s + 2 by
+    // a wave that has passed barrier s + 1, which every wave reaches only after its reads of this iteration
+    __builtin_amdgcn_s_barrier();
+    int so = (s % kWgRing) * W::kStage;
+    asm volatile("" : "+s"(so));
+    const unsigned char* st = lds + so;
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      // (not unrolled: with both halves of the stage in one block hipcc keeps ~44 fragments in flight and spills
+      // the NT = 8 accumulators)
+      const unsigned char* bt = st + 16 * kRowBytes * j;
+      const unsigned char* at = st + 16 * W::kPitch * j;
+      s16x8 bf[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) bf[jj] = tr_frag(bt + bbase[jj][0], bt + bbase[jj][1]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int imm = 256 * (i >> 2);
+        const s16x8 af = tr_frag(at + abase[i & 3] + imm, at + abase[i & 3] + imm + 4 * W::kPitch);
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          const s16x8 m_a = TR ? bf[jj] : af, m_b = TR ? af : bf[jj];
+          if (3 * i + jj >= 16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][jj]) : "v"(m_a), "v"(m_b));
+          else acc[i][jj] = mfma(m_a, m_b, acc[i][jj]);
+        }
+      }
+    }
+  }
+  // NT = 8: 24 accumulator tiles = 384 registers, 16 of them in the 256 AGPRs; hipcc only emits the AGPR form of an
+  // MFMA at one wave per SIMD and, left alone, swaps the other eight tiles through AGPRs around every MFMA (320 moves
+  // per 24 MFMAs): those eight are inline assembly on VGPR accumulators.  The assembler statements are invisible to
+  // the hazard recogniser, hence the wait states before the results are read.
+  if (NT == 8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  // ---- the chunk's partial: (Na, 384) row-major, or (384, Na) when TR
+  float* out = part + static_cast<long>(chunk) * Na * kC;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int d_row = (e & 3) + 8 * (e >> 2) + 4 * kh, d_col = lane & 31;
+        if (TR) out[static_cast<long>(96 * wave + 32 * jj + d_row) * Na + n0 + 32 * i + d_col] = acc[i][jj][e];
+        else out[static_cast<long>(n0 + 32 * i + d_row) * kC + 96 * wave + 32 * jj + d_col] = acc[i][jj][e];
+      }
+}
+
+__global__ __launch_bounds__(256) void wgrad384_reduce(const float4* __restrict__ part, float4* __restrict__ out, int n4, int n_chunks) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 s = part[e];
+  for (int ch = 1; ch < n_chunks; ++ch) {
+    const float4 v = part[static_cast<long>(ch) * n4 + e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[e] = s;
+}
+
 }  // namespace transoar
 
 using namespace transoar;
@@ -295,5 +462,43 @@ extern "C" int transoar_gemm_n384(const void* A, const void* B, const float* bia
     return TRANSOAR_GEMM_ERR_ALIGN;
   hipLaunchKernelGGL(gemm_n384_kernel, dim3(static_cast<unsigned>((M + 127) / 128)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                      static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(B), bias, static_cast<unsigned short*>(C), M, K);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_gemm_wgrad384_chunks(int T, int Na) {
+  if (T <= 0 || Na <= 0 || (Na & 127)) return 0;
+  const int tiles = (Na & 255) ? Na / 128 : Na / 256;
+  int chunks = 256 / tiles;
+  if (chunks < 1) chunks = 1;
+  const int len = ((T + chunks - 1) / chunks + 31) & ~31;
+  return (T + len - 1) / len;
+}
+
+extern "C" int transoar_gemm_wgrad384(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
+                                      int chunks, void* hip_stream) {
+  if (!A || !B || !part || !out) return TRANSOAR_GEMM_ERR_NULL;
+  if (T <= 0 || Na <= 0 || (Na & 127) || chunks <= 0) return TRANSOAR_GEMM_ERR_DIM;
+  if (static_cast<long>(T) * Na * 2 >= 0x7ffffff0L || static_cast<long>(T) * kRowBytes >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;   // 32-bit byte offsets
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15u)
+    return TRANSOAR_GEMM_ERR_ALIGN;
+  const bool wide = (Na & 255) == 0;
+  const int tiles = wide ? Na / 256 : Na / 128;
+  const int len = ((T + chunks - 1) / chunks + 31) & ~31;
+  if (static_cast<long>(len) * chunks < T) return TRANSOAR_GEMM_ERR_DIM;
+  const int n_chunks = (T + len - 1) / len;
+  if (n_chunks != chunks) return TRANSOAR_GEMM_ERR_DIM;             // the caller sized `part` with transoar_gemm_wgrad384_chunks
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const dim3 grid(static_cast<unsigned>(8 * tiles * ((n_chunks + 7) / 8)));
+  auto a = static_cast<const unsigned short*>(A);
+  auto b = static_cast<const unsigned short*>(B);
+  if (wide) {
+    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<8, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+    else hipLaunchKernelGGL((wgrad384_kernel<8, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+  } else {
+    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<4, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+    else hipLaunchKernelGGL((wgrad384_kernel<4, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+  }
+  const int n4 = Na * kC / 4;
+  hipLaunchKernelGGL(wgrad384_reduce, dim3((n4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), n4, n_chunks);
   return static_cast<int>(hipGetLastError());
 }

@@ -10,7 +10,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 STREAM_SQUARE = os.environ.get("TRANSOAR_GEMM_STREAM_SQUARE", "0") == "1"
 STREAM_N384 = os.environ.get("TRANSOAR_GEMM_N384", "0") == "1"
 STREAM = os.environ.get("TRANSOAR_GEMM_STREAM", "1") != "0"      # the K = 384 / N = 384 streaming kernels (csrc/gemm_stream.hip)
@@ -30,6 +30,10 @@ def _load():
     lib.transoar_gemm_k384_drop.argtypes = [p, p, p, p, i, i, i, p, ctypes.c_float, ctypes.c_float, p]
     lib.transoar_gemm_n384.restype = i
     lib.transoar_gemm_n384.argtypes = [p, p, p, p, i, i, p]
+    lib.transoar_gemm_wgrad384_chunks.restype = i
+    lib.transoar_gemm_wgrad384_chunks.argtypes = [i, i]
+    lib.transoar_gemm_wgrad384.restype = i
+    lib.transoar_gemm_wgrad384.argtypes = [p, p, p, p, i, i, i, i, p]
     lib.transoar_gemm_abi_version.restype = i
     if lib.transoar_gemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -112,4 +116,37 @@ def linear_relu_dropout(x, w, bias, seed, keep_prob):
                                          torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("transoar_gemm_k384_drop failed with code %d" % rc)
+    return out
+
+
+WGRAD384 = os.environ.get("TRANSOAR_GEMM_WGRAD384", "1") != "0"
+
+
+def wgrad384_usable(gy, x):
+    """The token-streaming weight gradient (csrc/gemm_stream.hip, wgrad384_kernel): dense bf16 (T, n) / (T, k) with 384
+    channels on one side, a multiple of 128 on the other, enough tokens for one workgroup per CU."""
+    if not (WGRAD384 and gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.dim() == 2 and x.dim() == 2
+            and gy.is_contiguous() and x.is_contiguous() and gy.shape[0] == x.shape[0] and gy.shape[0] >= 16384):
+        return False
+    n, k = gy.shape[1], x.shape[1]
+    other = n if k == 384 else (k if n == 384 else 0)
+    return other > 0 and other % 128 == 0 and gy.shape[0] * max(other, 384) * 2 < 0x7ffffff0
+
+
+def wgrad384(gy, x):
+    """gy (T, n), x (T, k) -> dW (n, k) fp32 = gy^T x."""
+    t, n = gy.shape
+    k = x.shape[1]
+    if k == 384:
+        a, b, na, tr = gy, x, n, 0
+    else:
+        a, b, na, tr = x, gy, k, 1
+    chunks = lib.transoar_gemm_wgrad384_chunks(t, na)
+    part = torch.empty((chunks, n, k), dtype=torch.float32, device=gy.device)
+    out = torch.empty((n, k), dtype=torch.float32, device=gy.device)
+    with torch.cuda.device(gy.device):
+        rc = lib.transoar_gemm_wgrad384(a.data_ptr(), b.data_ptr(), part.data_ptr(), out.data_ptr(), t, na, tr, chunks,
+                                        torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_wgrad384 failed with code %d" % rc)
     return out

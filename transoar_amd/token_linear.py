@@ -64,6 +64,8 @@ def weight_grad(gy, x):
     """(T, N)^T @ (T, K) -> (N, K) fp32: the token axis is the contraction."""
     t, n = gy.shape
     k = x.shape[1]
+    if USE_HIP_WGRAD and gemm.wgrad384_usable(gy, x):
+        return gemm.wgrad384(gy, x)
     if (USE_HIP_WGRAD and gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.is_contiguous()
             and x.is_contiguous() and n % 8 == 0 and k % 8 == 0 and t < (1 << 21)):
         return conv_gemm.linear_wgrad(x, gy)
