@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Each workgroup writes its fp32 partial (its chunk of tokens); wgrad384_reduce sums the chunks.
 // Block order: the NT-tiles of one token chunk sit on the same XCD (block % 8) next to each other, so the chunk's
 // B tiles come from that XCD's L2 for all but the first of them.
-constexpr int kWgRing = 4;
 template <int NT> struct WgTile {
+  static constexpr int kRing = NT == 4 ? 5 : 4;         // 5 x 32 KiB / 4 x 40 KiB = all of the CU's LDS
+  static constexpr int kAhead = kRing - 2;              // stages in flight beyond the one being read
   static constexpr int kPitch = 64 * NT;                // bytes per token row of the A tile
   static constexpr int kABytes = 32 * kPitch;
   static constexpr int kStage = kTile + kABytes;        // 32 / 40 KiB
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ part,
     int T, int Na, int chunk_len, int n_chunks, int n_tiles) {
   using W = WgTile<NT>;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[kWgRing * W::kStage];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[W::kRing * W::kStage];
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
   const int tile = by % n_tiles, chunk = (by / n_tiles) * 8 + bx;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const unsigned a_soff0 = static_cast<unsigned>(t0) * lda_bytes + static_cast<unsigned>(n0) * 2u;
   auto issue = [&](int s) {
-    unsigned char* stg = lds + (s % kWgRing) * W::kStage;
+    unsigned char* stg = lds + (s % W::kRing) * W::kStage;
     dma_tile(brs, static_cast<unsigned>(t0 + 32 * s) * static_cast<unsigned>(kRowBytes), stg, wave, lane);
 #pragma unroll
     for (int j = 0; j < W::kPerWave; ++j)
@@ -347,25 +348,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   issue(0);
   if (n_stages > 1) issue(1);
+  if (W::kAhead > 2 && n_stages > 2) issue(2);
   for (int s = 0; s < n_stages; ++s) {
-    if (s + 2 < n_stages) {
-      issue(s + 2);
+    // the waits count DMA instructions (kIssue per stage and wave, in issue order)
+    if (s + W::kAhead < n_stages) {
+      issue(s + W::kAhead);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::kAhead * W::kIssue) : "memory");
+    } else if (W::kAhead > 2 && s + 2 < n_stages) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W::kIssue) : "memory");
     } else if (s + 1 < n_stages) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::kIssue) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // one barrier per stage: the stage read here is overwritten by stage s + 4, issued at the top of iteration s + 2 by
-    // a wave that has passed barrier s + 1, which every wave reaches only after its reads of this iteration
+    // one barrier per stage: the stage read here is overwritten by stage s + kRing, issued at the top of iteration s + 2
+    // by a wave that has passed barrier s + 1, which every wave reaches only after its reads of this iteration
     __builtin_amdgcn_s_barrier();
-    int so = (s % kWgRing) * W::kStage;
+    int so = (s % W::kRing) * W::kStage;
     asm volatile("" : "+s"(so));
     const unsigned char* st = lds + so;
-#pragma unroll 1
+    // (NT = 8 not unrolled: with both halves of the stage in one block hipcc keeps ~44 fragments in flight and spills
+    // the accumulators; NT = 4 unrolled: the second half's reads overlap the first half's MFMAs)
+#pragma unroll(NT == 4 ? 2 : 1)
     for (int j = 0; j < 2; ++j) {
-      // (not unrolled: with both halves of the stage in one block hipcc keeps ~44 fragments in flight and spills
-      // the NT = 8 accumulators)
       const unsigned char* bt = st + 16 * kRowBytes * j;
       const unsigned char* at = st + 16 * W::kPitch * j;
       s16x8 bf[3];
@@ -403,15 +408,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
 }
 
+// out[e] = sum over the chunks of part[chunk][e]: 32 float4 elements per workgroup, eight lanes of chunks each (a
+// thread sums chunks g, g + 8, ...), then across the eight through LDS in a fixed order
 __global__ __launch_bounds__(256) void wgrad384_reduce(const float4* __restrict__ part, float4* __restrict__ out, int n4, int n_chunks) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  float4 s = part[e];
-  for (int ch = 1; ch < n_chunks; ++ch) {
-    const float4 v = part[static_cast<long>(ch) * n4 + e];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  __shared__ float4 sh[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float4 s{0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+#pragma unroll 4
+    for (int ch = g; ch < n_chunks; ch += 8) {
+      const float4 v = part[static_cast<long>(ch) * n4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  out[e] = s;
+  sh[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && e < n4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 v = sh[k][threadIdx.x];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[e] = s;
+  }
 }
 
 }  // namespace transoar
@@ -499,6 +518,6 @@ extern "C" int transoar_gemm_wgrad384(const void* A, const void* B, float* part,
     else hipLaunchKernelGGL((wgrad384_kernel<4, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
   }
   const int n4 = Na * kC / 4;
-  hipLaunchKernelGGL(wgrad384_reduce, dim3((n4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), n4, n_chunks);
+  hipLaunchKernelGGL(wgrad384_reduce, dim3((n4 + 31) / 32), dim3(256), 0, st, reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), n4, n_chunks);
   return static_cast<int>(hipGetLastError());
 }

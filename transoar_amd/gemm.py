@@ -122,15 +122,24 @@ def linear_relu_dropout(x, w, bias, seed, keep_prob):
 WGRAD384 = os.environ.get("TRANSOAR_GEMM_WGRAD384", "1") != "0"
 
 
-def wgrad384_usable(gy, x):
-    """The token-streaming weight gradient (csrc/gemm_stream.hip, wgrad384_kernel): dense bf16 (T, n) / (T, k) with 384
-    channels on one side, a multiple of 128 on the other, enough tokens for one workgroup per CU."""
-    if not (WGRAD384 and gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.dim() == 2 and x.dim() == 2
-            and gy.is_contiguous() and x.is_contiguous() and gy.shape[0] == x.shape[0] and gy.shape[0] >= 16384):
-        return False
+def wgrad384_shapes(gy, x):
+    """What the kernel can take at all: dense bf16 (T, n) / (T, k), 384 channels on one side, a multiple of 128 on the other."""
+    if not (gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.dim() == 2 and x.dim() == 2
+            and gy.is_contiguous() and x.is_contiguous() and gy.shape[0] == x.shape[0]):
+        return 0
     n, k = gy.shape[1], x.shape[1]
     other = n if k == 384 else (k if n == 384 else 0)
-    return other > 0 and other % 128 == 0 and gy.shape[0] * max(other, 384) * 2 < 0x7ffffff0
+    return other if (other > 0 and other % 128 == 0 and gy.shape[0] * max(other, 384) * 2 < 0x7ffffff0) else 0
+
+
+def wgrad384_usable(gy, x):
+    """Where the token-streaming weight gradient (csrc/gemm_stream.hip, wgrad384_kernel) is the faster one: 256-wide
+    column tiles (the other side a multiple of 256) and at most four of them -- every workgroup streams the whole
+    384-channel operand through LDS-DMA, whose chip-wide rate (~6 TB/s, MI355X_MICROARCH.md "ldsdma-fill") is what bounds
+    the kernel: 234 000 x 1024 x 384 in 0.21 ms against the one-tap conv GEMM's 0.29, but 384 x 384 (128-wide tiles)
+    0.143 against 0.109 and 384 x 3072 0.83 against 0.73 (profiles/r04_gemm_bench.jsonl)."""
+    other = wgrad384_shapes(gy, x)
+    return WGRAD384 and other % 256 == 0 and 0 < other <= 1024 and gy.shape[0] >= 16384
 
 
 def wgrad384(gy, x):
