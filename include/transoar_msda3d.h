@@ -64,7 +64,9 @@ enum {
   TRANSOAR_ERR_ALIGN = -4,       /* a buffer is not 16-byte aligned       */
   TRANSOAR_ERR_LEVELS = -5,      /* L > TRANSOAR_MSDA3D_MAX_LEVELS        */
   TRANSOAR_ERR_WORKSPACE = -6,   /* workspace smaller than required       */
-  TRANSOAR_ERR_CONST = -7        /* device copy of the launch constants could not be made (first call for a shape inside a stream capture) */
+  TRANSOAR_ERR_CONST = -7,       /* device copy of the launch constants could not be made (first call for a shape inside a stream capture) */
+  TRANSOAR_ERR_MODE = -8         /* TRANSOAR_MSDA3D_DETERMINISTIC asked for a form it does not cover (it covers the flagship form: 16-bit storage,
+                                  * 64 channels, 4 points, <= 4 levels known on the host, queries = voxels of the pyramid) */
 };
 
 #define TRANSOAR_MSDA3D_MAX_LEVELS 8
@@ -75,6 +77,11 @@ enum {
 #define TRANSOAR_MSDA3D_FORK 8u             /* backward: run the coarse-level grad_value walk on an internal side stream */
 #define TRANSOAR_MSDA3D_NO_MMA 16u            /* forward: LDS-tiled per-corner kernel instead of the matrix-core gather */
 #define TRANSOAR_MSDA3D_MMA_Q32 32u           /* forward: round 2's matrix-core gather (32 queries per wave, fp32 weight block) instead of the point-column one */
+#define TRANSOAR_MSDA3D_DETERMINISTIC 64u      /* backward: bit-stable grad_value.  The sampling points are ordered by (cell, canonical
+                                                * point index) with a stable radix sort instead of by the arrival order of atomic
+                                                * cursors, and every level is accumulated by the brick-owner walk (no fp32 row atomics).
+                                                * A test mode ("deterministic-mode backward"): ~4x the default backward's time;
+                                                * the workspace query must be made with the same flags. */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*

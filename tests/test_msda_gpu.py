@@ -597,3 +597,70 @@ def test_full_size_grad_value_elementwise_vs_torch_oracle(MSDA):
     # land in the neighbouring cell.  Everything else agrees to 1e-4.
     d = (gl.double().cpu() - lc.grad.double()).abs() / float(lc.grad.abs().max())
     assert float((d > 1e-4).double().mean()) <= 1e-5, float((d > 1e-4).double().mean())
+
+
+# ---------------------------------------------------------------------------
+# deterministic-mode backward (TRANSOAR_MSDA3D_DETERMINISTIC): bit-stable grad_value
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("geom,dist", [("visceral", "model"), ("visceral", "oob"), ("amos", "uniform"), ("amos", "init")])
+def test_deterministic_backward_is_bit_stable_and_agrees_with_default(MSDA, geom, dist):
+    """Three runs in deterministic mode give bit-identical gradients (the default order depends on the arrival order of
+    atomic cursors and on fp32 row atomics: its runs differ at fp32 rounding level), and the mode computes the same
+    gradients as the default chain: grad_loc / grad_attn bit-identical (same kernel, no atomics there), grad_value to bf16
+    output rounding."""
+    value, shapes, lsi, loc, attn = _full_size_case(geom, dist)
+    v = value.to(torch.bfloat16)
+    N, S, M, C = v.shape
+    go = torch.randn(N, S, M * C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(29)).to(torch.bfloat16)
+    MSDA.flags = 0
+    ref = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+    MSDA.deterministic = True
+    try:
+        runs = []
+        for _ in range(3):
+            runs.append(MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64))
+            torch.cuda.synchronize()
+            # something else on the GPU in between, so that the runs do not see the same scheduling state
+            torch.randn(1 << 22, device="cuda").sum().item()
+    finally:
+        MSDA.deterministic = False
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+    assert not torch.isnan(runs[0][0].float()).any()
+    assert torch.equal(runs[0][1], ref[1]) and torch.equal(runs[0][2], ref[2])
+    assert relerr(runs[0][0], ref[0]) <= TOL[torch.bfloat16]
+    assert elem_relerr(runs[0][0], ref[0]) <= ELEM_TOL[torch.bfloat16]
+
+
+def test_deterministic_mode_follows_torch_switch_and_refuses_uncovered_forms(MSDA):
+    """torch.use_deterministic_algorithms(True) selects the mode; a form it does not cover (fp32 storage) raises like torch's
+    own ops without a deterministic implementation, warns and runs the default order under warn_only."""
+    value, shapes, lsi, loc, attn = _full_size_case("amos", "model")
+    v = value.to(torch.bfloat16)
+    go = torch.randn(v.shape[0], v.shape[1], 6 * 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)).to(torch.bfloat16)
+    MSDA.flags = 0
+    MSDA.deterministic = True
+    try:
+        want = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+    finally:
+        MSDA.deterministic = False
+    torch.use_deterministic_algorithms(True)
+    try:
+        got = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        with pytest.raises(RuntimeError, match="deterministic"):
+            MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go.float(), 64)
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match="deterministic"):
+            gv = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go.float(), 64)[0]
+        assert not torch.isnan(gv).any()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    MSDA.deterministic = True
+    try:
+        with pytest.raises(RuntimeError, match="deterministic"):          # the strict switch: no fall-back at all
+            MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go.float(), 64)
+    finally:
+        MSDA.deterministic = False

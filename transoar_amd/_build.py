@@ -21,7 +21,7 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"
 
 # library name -> sources (relative to csrc/)
 LIBS = {
-    "libtransoar_msda3d.so": ["msda3d.hip"],
+    "libtransoar_msda3d.so": ["msda3d.hip", "msda3d_sort.hip"],
     "libtransoar_conv3d.so": ["conv3d.hip"],
     "libtransoar_instnorm.so": ["instnorm.hip"],
     "libtransoar_rows.so": ["rows.hip"],

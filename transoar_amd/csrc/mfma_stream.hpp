@@ -58,12 +58,14 @@ __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 
 // hipcc neither counts these loads nor waits for them: every tile loop ends with dma_wait() before its barrier, and
 // nothing else in the loops is a vector memory operation.  M0 (the LDS destination base) is saved and restored in
 // the statement that uses it; the leading s_nop covers the SGPR-write -> VMEM-read hazard of freshly computed operands.
+template <int WAVES = 4>      // waves of the workgroup sharing the tile: 24 / WAVES pieces each
 __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, unsigned tile_byte, unsigned char* lds_tile, int wave, int lane) {
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_tile));
   const unsigned soff = __builtin_amdgcn_readfirstlane(tile_byte);
+  constexpr int kPer = 24 / WAVES;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int piece = 6 * wave + j;
+  for (int j = 0; j < kPer; ++j) {
+    const int piece = kPer * wave + j;
     const int o = piece * 1024 + 16 * lane;
     const int n = ((o >> 8) * 171) >> 9;                 // o / 768 for o < 24 576
     const int q = (o - n * kRowBytes) >> 4;               // physical 16-byte piece inside the row

@@ -195,11 +195,14 @@ static inline int vec_lpv(const Dims& d, int elt, unsigned flags) {
 }
 
 struct BwdWorkspace {
-  size_t count, tile_sums, rank, rec_item, recs, coarse, total;
+  size_t count, tile_sums, rank, rec_item, recs, coarse, det_keys, det_alt, det_temp, det_temp_bytes, total;
   long n_bins, n_points, n_scan, n_tiles;
 };
 
-static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
+int sort_keys64(unsigned long long* keys, unsigned long long* alt, long n, int end_bit, void* temp, size_t* temp_bytes,
+                unsigned long long** sorted, hipStream_t st);          // msda3d_sort.hip
+
+static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size, unsigned flags = 0u) {
   BwdWorkspace w;
   w.n_points = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
   w.n_bins = static_cast<long>(d.N) * d.M * 8 * d.S;   // (D+1)(H+1)(W+1) <= 8*D*H*W
@@ -212,6 +215,14 @@ static BwdWorkspace bwd_workspace(const Dims& d, size_t acc_size) {
   w.rec_item = off;  off += align16(sizeof(int) * w.n_points);
   w.recs = off;      off += align16(8 * acc_size * w.n_points);   // PointW8 (tile path) or PointRec
   w.coarse = off;    off += align16(sizeof(float) * static_cast<size_t>(d.N) * d.S * d.M * d.C);   // fp32 rows of the coarse levels
+  w.det_keys = w.det_alt = w.det_temp = off;
+  w.det_temp_bytes = 0;
+  if (flags & TRANSOAR_MSDA3D_DETERMINISTIC) {      // two key buffers + the radix sort's scratch (histograms: a bound, checked at run time)
+    w.det_keys = off;  off += align16(sizeof(unsigned long long) * w.n_points);
+    w.det_alt = off;   off += align16(sizeof(unsigned long long) * w.n_points);
+    w.det_temp_bytes = align16((size_t(32) << 20) + static_cast<size_t>(w.n_points));
+    w.det_temp = off;  off += w.det_temp_bytes;
+  }
   w.total = off;
   return w;
 }
@@ -344,10 +355,20 @@ static int launch_fwd_fused(const void* value, const void* proj, const float* re
   return static_cast<int>(hipGetLastError());
 }
 
+// deterministic mode: sorted position j takes the record of the canonical slot in the low half of its key
+__global__ __launch_bounds__(256) void msda3d_det_gather(const unsigned long long* __restrict__ sorted, const PointR16* __restrict__ slots,
+                                                          PointR16* __restrict__ recs, long n) {
+  const long j = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long k = sorted[j];
+  if (k == ~0ull) return;
+  recs[j] = slots[static_cast<unsigned>(k)];
+}
+
 template <typename VT, typename LT>
 static size_t bwd_workspace_bytes(const Dims& d, unsigned flags) {
   using A = typename Elem<VT>::acc;
-  if (vec_lpv(d, sizeof(VT), flags) >= 0) return bwd_workspace(d, sizeof(A)).total;
+  if (vec_lpv(d, sizeof(VT), flags) >= 0) return bwd_workspace(d, sizeof(A), flags).total;
   // generic path: fp32 accumulator for 16-bit storage
   return sizeof(VT) == 2 ? align16(sizeof(float) * static_cast<size_t>(d.N) * d.S * d.M * d.C) : 0;
 }
@@ -398,7 +419,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 
   const dim3 grid(((n_blocks + 7) / 8) * 8);
   const unsigned vbytes = static_cast<unsigned>(value_elems * sizeof(VT));
-  const BwdWorkspace w = bwd_workspace(d, sizeof(A));
+  const BwdWorkspace w = bwd_workspace(d, sizeof(A), flags);
   char* ws = static_cast<char*>(workspace);
   int* count = reinterpret_cast<int*>(ws + w.count);
   int* tile_sums = reinterpret_cast<int*>(ws + w.tile_sums);
@@ -414,7 +435,9 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   const bool fold_count = host_shapes != nullptr && cells_per_slab * d.N * d.M <= w.n_bins;
   // entries of the count / offset array that are in use: one per cell + the end of the last run (the upper bound
   // n_bins + 1 = 8 S N M + 1 without host shapes: zeroing and scanning it was 45 MB four times over at the flagship size)
-  const long n_scan = fold_count ? cells_per_slab * d.N * d.M + 1 : w.n_scan;
+  // (deterministic mode reads the walks' offsets one entry further on -- see below -- hence one more scanned entry)
+  const bool det_req = (flags & TRANSOAR_MSDA3D_DETERMINISTIC) != 0;
+  const long n_scan = fold_count ? cells_per_slab * d.N * d.M + 1 + (det_req && cells_per_slab * d.N * d.M + 2 <= w.n_scan ? 1 : 0) : w.n_scan;
   const long n_tiles = (n_scan + kScanTile - 1) / kScanTile;
   TRANSOAR_CHECK_HIP(zero_async(count, sizeof(int) * n_scan, st));
   auto scan = [&]() {
@@ -432,7 +455,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
   hipLaunchKernelGGL((msda3d_bwd_query_vec<VT, LT, LG>), grid, block, 0, st, v, shapes, lsi, lo, \
                      at, go, gl, ga, fold_count ? count : nullptr, rank, static_cast<int>(cells_per_slab), \
                      d.S, d.M, d.C, d.L, d.Lq, d.P, vbytes, q_units, n_blocks, q_order)
-  bool brick_done = false, recs_done = false;
+  bool brick_done = false, recs_done = false, det = false;
   if constexpr (sizeof(VT) == 2) {
     bool small = d.L <= kMmaLevels;
     for (int l = 0; small && l < d.L; ++l) small = q_order.D[l] <= 1000 && q_order.H[l] <= 1000 && q_order.W[l] <= 1000;
@@ -453,13 +476,47 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
                            static_cast<int>(cells_per_slab), d.S, d.M, d.L, n_wave, order_d);
       }
       scan();
-      ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
-      hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
-                         v, lo, at, go, gl, ga, count + 1, reinterpret_cast<PointR16*>(ws + w.recs),
-                         static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+      det = det_req && cells_per_slab * d.N * d.M + 2 <= w.n_scan && w.n_points < (1L << 32);
+      if (det_req && !det) return TRANSOAR_ERR_MODE;
+      if (!det) {
+        ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+        hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
+                           v, lo, at, go, gl, ga, count + 1, reinterpret_cast<PointR16*>(ws + w.recs), nullptr,
+                           static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+      } else {
+        // Deterministic order: every point's record goes to its canonical slot (upper half of the record region) with
+        // the key (cell << 32 | slot); a stable radix sort of the keys (skipped points keep the all-ones key and end up
+        // last) and one gather put the records of a cell next to each other in slot order.  The exclusive scan of the
+        // counts is left as it is (no cursor advanced): count[c + 1] is the FIRST position of cell c, i.e. the walks
+        // read their (offset[c], offset[c + 1]) pairs from count + 1.
+        auto keys = reinterpret_cast<unsigned long long*>(ws + w.det_keys);
+        auto alt = reinterpret_cast<unsigned long long*>(ws + w.det_alt);
+        PointR16* slots = reinterpret_cast<PointR16*>(ws + w.recs) + w.n_points;
+        TRANSOAR_CHECK_HIP(hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * w.n_points, st));
+        {
+          ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
+          hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
+                             v, lo, at, go, gl, ga, count + 1, slots, keys,
+                             static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+        }
+        ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
+        int cell_bits = 1;
+        while ((cells_per_slab * d.N * d.M) >> cell_bits) ++cell_bits;
+        size_t need = 0;
+        int rc = sort_keys64(keys, alt, w.n_points, 32 + cell_bits, nullptr, &need, nullptr, st);
+        if (rc != 0) return rc;
+        if (need > w.det_temp_bytes) return TRANSOAR_ERR_WORKSPACE;
+        unsigned long long* sorted = nullptr;
+        size_t temp_bytes = w.det_temp_bytes;
+        rc = sort_keys64(keys, alt, w.n_points, 32 + cell_bits, ws + w.det_temp, &temp_bytes, &sorted, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(msda3d_det_gather, dim3(static_cast<unsigned>((w.n_points + 255) / 256)), dim3(256), 0, st,
+                           sorted, slots, reinterpret_cast<PointR16*>(ws + w.recs), w.n_points);
+      }
       brick_done = recs_done = true;
     }
   }
+  if (det_req && !det) return TRANSOAR_ERR_MODE;           // no silent fall-back to an order that depends on atomics
   if constexpr (sizeof(VT) == 2) {
     if (!brick_done && q_order.enabled && fold_count && d.C == 64 && d.P == 4 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
       ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
@@ -505,7 +562,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
       }
       // levels whose voxels receive >= kCoarsePointsPerVoxel points each go to the chunked walk
       CoarseLevels cl{d.L, static_cast<int>(cells_per_slab), d.S, 0, 0};
-      for (int l = d.L - 1; l >= 0; --l) {
+      const int* offsets = det ? count + 1 : count;
+      for (int l = d.L - 1; l >= 0 && !det; --l) {          // deterministic mode: no coarse level (their walk flushes with fp32 atomics)
         const long vox = host_shapes[3 * l] * host_shapes[3 * l + 1] * host_shapes[3 * l + 2];
         if (static_cast<long>(d.Lq) * d.P < kCoarsePointsPerVoxel * vox) break;
         cl.first = l;
@@ -539,7 +597,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         if (mma) {
           if constexpr (sizeof(VT) == 2)       // 16 sorted points per MFMA K-step (msda3d_cells_mma.hpp)
             hipLaunchKernelGGL((msda3d_bwd_value_cells_mma<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0,
-                               cst, go, count, recs4, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
+                               cst, go, offsets, recs4, scratch, static_cast<int>(cells_per_slab), d.N * d.M, d.M,
                                cl_d, r_order_d);
         } else {
           hipLaunchKernelGGL((msda3d_bwd_value_cells<VT>), dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, cst,
@@ -554,7 +612,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         if (mma) {
           if constexpr (sizeof(VT) == 2)
             hipLaunchKernelGGL((msda3d_bwd_value_tile_mma<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st,
-                               go, count, recs4, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
+                               go, offsets, recs4, static_cast<VT*>(grad_value), static_cast<int>(cells_per_slab),
                                d.S, d.M, fine_bricks, n_wg, r_order_d);
         } else {
           hipLaunchKernelGGL((msda3d_bwd_value_tile<VT>), dim3(static_cast<unsigned>(n_wg)), dim3(kBrickThreads), 0, st, go,
@@ -703,6 +761,7 @@ extern "C" const char* transoar_msda3d_strerror(int code) {
     case TRANSOAR_ERR_ALIGN: return "a device buffer is not 16-byte aligned";
     case TRANSOAR_ERR_LEVELS: return "too many feature levels";
     case TRANSOAR_ERR_WORKSPACE: return "workspace is smaller than transoar_msda3d_backward_workspace_bytes()";
+    case TRANSOAR_ERR_MODE: return "the deterministic backward does not cover this form (16-bit storage, C = 64, P = 4, <= 4 host-known levels, queries = pyramid voxels)";
     case TRANSOAR_ERR_CONST: return "could not place the launch constants in device memory (first call for a shape must not be inside a stream capture)";
     default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
   }

@@ -498,8 +498,8 @@ template <typename VT, typename LT>
 __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
     const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
-    int* __restrict__ cursor, PointR16* __restrict__ recs, int cells_per_slab, int S, int M, int L,
-    unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
+    int* __restrict__ cursor, PointR16* __restrict__ recs, unsigned long long* __restrict__ det_keys, int cells_per_slab,
+    int S, int M, int L, unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
   const BrickOrder& order = *order_p;
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
@@ -598,7 +598,21 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     // cursor[cell] holds the next free position of the cell's run (the counting pre-pass msda3d_cell_count_mma and the
     // scan put the run's first position there): a wave reserves the places of all its points of a cell with ONE
     // returning atomic (LDS histogram over the wave's cell box first) and writes the records there and then.
-    if (cursor != nullptr) {
+    if (det_keys != nullptr) {
+      // deterministic mode: the record goes to the point's canonical slot, together with the key (cell, slot) that the
+      // stable sort of the host chain orders the points by -- no cursors, no arrival order
+      const long slab_cell = static_cast<long>(b * M + m) * cells_per_slab + my_cell_start;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const MmaPoint g = pt[l][pi];
+        if (g.dhw == 0x3fffffff) continue;
+        const int c1d = g.dhw & 1023, c1h = (g.dhw >> 10) & 1023, c1w = (g.dhw >> 20) & 1023;
+        const unsigned long long cell = static_cast<unsigned long long>(slab_cell + (c1d * (H + 1) + c1h) * (W + 1) + c1w);
+        const unsigned slot = static_cast<unsigned>(item) * static_cast<unsigned>(LP) + static_cast<unsigned>(l * P + 2 * kg + pi);
+        recs[slot] = make_point_r16(g.a, static_cast<int>(item), g.ld, g.lh, g.lw);
+        det_keys[slot] = (cell << 32) | slot;
+      }
+    } else if (cursor != nullptr) {
       int* slab_cursor = cursor + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
       int* hist = reinterpret_cast<int*>(gbuf);
       const int CH = bx.TH + 1, CW = bx.TW + 1;

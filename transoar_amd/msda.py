@@ -27,6 +27,14 @@ _DT = {torch.float32: _native.F32, torch.float64: _native.F64,
 # bit set forwarded to the C ABI (see include/transoar_msda3d.h); module-level so
 # tests can force the generic kernels.
 flags = int(os.environ.get("TRANSOAR_MSDA_FLAGS", "0"))
+DETERMINISTIC = 64      # TRANSOAR_MSDA3D_DETERMINISTIC
+ERR_MODE = -8           # TRANSOAR_ERR_MODE
+# Bit-stable backward ("deterministic-mode backward"): grad_value is accumulated in an order that does not depend
+# on atomics (stable sort of the points by (cell, point index), brick-owner walk on every level) -- about 4x the default
+# backward's time.  On when this switch is set (strict: a form the mode does not cover raises) or when
+# torch.use_deterministic_algorithms(True) is in force (a form that is not covered raises like torch's own ops do, or warns
+# and runs the default order under warn_only=True).  grad_sampling_loc / grad_attn_weight and the forward have no atomics.
+deterministic = os.environ.get("TRANSOAR_MSDA_DETERMINISTIC", "0") == "1"
 
 
 # host copy of a spatial_shapes tensor, kept ON the tensor object (it dies with it; an address-keyed
@@ -165,15 +173,32 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     dims = (N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype])
-    ws_bytes = _native.lib.transoar_msda3d_backward_workspace_bytes(*dims, flags)
-    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=value.device)
     _keep, host_ptr = _shapes_on_host(spatial_shapes)
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream().cuda_stream
-        rc = _native.lib.transoar_msda3d_backward(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-            workspace.data_ptr(), ws_bytes, *dims, host_ptr, flags, stream)
+    torch_det = torch.are_deterministic_algorithms_enabled()
+
+    def run(call_flags):
+        ws_bytes = _native.lib.transoar_msda3d_backward_workspace_bytes(*dims, call_flags)
+        workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=value.device)
+        with torch.cuda.device(value.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            return _native.lib.transoar_msda3d_backward(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                workspace.data_ptr(), ws_bytes, *dims, host_ptr, call_flags, stream)
+
+    if deterministic or torch_det or (flags & DETERMINISTIC):
+        rc = run(flags | DETERMINISTIC)
+        if rc == ERR_MODE and not (deterministic or (flags & DETERMINISTIC)):
+            if not torch.is_deterministic_algorithms_warn_only_enabled():
+                raise RuntimeError("ms_deform_attn_backward does not have a deterministic implementation for this form (16-bit "
+                                   "storage, 64 channels, 4 points, <= 4 levels with queries = the pyramid's voxels are covered), "
+                                   "but torch.use_deterministic_algorithms(True) is set; use warn_only=True to run the default order")
+            import warnings
+            warnings.warn("ms_deform_attn_backward: no deterministic implementation for this form; running the default "
+                          "(atomic-order dependent) accumulation")
+            rc = run(flags)
+    else:
+        rc = run(flags)
     _native.check(rc, "transoar_msda3d_backward")
     return [grad_value, grad_loc.to(loc_in_dtype), grad_attn.to(attn_in_dtype)]
