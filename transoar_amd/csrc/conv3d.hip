@@ -38,10 +38,14 @@ using u32x4c = __attribute__((ext_vector_type(4))) unsigned int;
 using u32x2c = __attribute__((ext_vector_type(2))) unsigned int;
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<unsigned short>(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+// (bf16(b) << 16) | bf16(a), round to nearest even: one v_cvt_pk_bf16_f32 (the integer sequence of f2bf is 7 VALU
+// instructions per value; conv3d_k3_lds spent a fifth of its 7 800 VALU instructions per wave there)
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(unsigned short b) {
   return __uint_as_float(static_cast<unsigned int>(b) << 16);
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_igemm(const unsigned short* __r
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[a][t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
           u32x2c pk;
-          pk[0] = static_cast<unsigned>(f2bf(o[0])) | (static_cast<unsigned>(f2bf(o[1])) << 16);
-          pk[1] = static_cast<unsigned>(f2bf(o[2])) | (static_cast<unsigned>(f2bf(o[3])) << 16);
+          pk[0] = pack2_bf16(o[0], o[1]);
+          pk[1] = pack2_bf16(o[2], o[3]);
           *reinterpret_cast<u32x2c*>(yrow + co) = pk;
         }
       }
@@ -309,6 +313,51 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
   const unsigned w_lane = static_cast<unsigned>(col) * g.CinP * 2u;
   const bool co_ok = col < g.Cout;
   const unsigned w_tap = static_cast<unsigned>(g.Cout) * g.CinP * 2u;       // bytes per tap
+  if constexpr (CPT == 3 && !C1) {
+    // 24 channels (round 4).  The loop below reads one activation fragment per MFMA: 1 KiB of LDS per 32 matrix-core
+    // cycles and wave, i.e. the CU's LDS pipe (128 B/clk) and its matrix cores saturate together and each ends up half
+    // idle (0.70 ms on 24 -> 24 at 160 x 160 x 256 against 0.29 ms of MFMA time).  The fragment of output row t at
+    // filter row kh is halo row t + kh: ordering K so that the three kh of one (kw, channel-chunk pair) are adjacent,
+    // SIX row reads serve the TWELVE MFMAs of a group (3 kh x 4 output rows).  Per kd plane five groups:
+    //   kw = 0, 1, 2:  half 0 takes channels 0-7, half 1 channels 8-15 of tap (kh, kw)
+    //   group 3:       channels 16-23 of taps (kh, 0) | (kh, 1);   group 4: channels 16-23 of tap (kh, 2) | nothing
+    // 15 K-steps per plane instead of 14 (+7 % MFMAs), half the LDS reads.  The three weight fragments of a group are
+    // fetched a group ahead (global, L1-resident).
+    auto load_w = [&](auto gc, int kd, bf16x8 (&wf)[3]) {
+      constexpr int gi = decltype(gc)::value;
+      constexpr int kw0 = gi < 3 ? gi : (gi == 3 ? 0 : 2), kw1 = gi < 3 ? gi : (gi == 3 ? 1 : 2);
+      constexpr int c80 = gi < 3 ? 0 : 2, c81 = gi < 3 ? 1 : 2;
+      const bool ok = co_ok && (half ? gi != 4 : true);
+      const unsigned base = kd * 9 * w_tap + w_lane + (half ? kw1 * w_tap + c81 * 16 : kw0 * w_tap + c80 * 16);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+        wf[kh] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, ok ? base + kh * 3 * w_tap : kOOB, 0, 0));
+    };
+    bf16x8 wcur[3];
+    load_w(ConvIntC<0>{}, 0, wcur);
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+      const unsigned char* plane = lane_base + kd * (kLtH + 2) * (kLtW + 2) * VP;
+      static_for_conv<0, 5>([&](auto gc) {
+        constexpr int gi = decltype(gc)::value;
+        constexpr int kw0 = gi < 3 ? gi : (gi == 3 ? 0 : 2), kw1 = gi < 3 ? gi : (gi == 3 ? 1 : 2);
+        constexpr int c80 = gi < 3 ? 0 : 2, c81 = gi < 3 ? 1 : 2;
+        bf16x8 wnext[3];
+        if constexpr (gi + 1 < 5) load_w(ConvIntC<gi + 1>{}, kd, wnext);
+        else load_w(ConvIntC<0>{}, kd + 1, wnext);             // (kd + 1 == 3: past the filter, reads zeros, unused)
+        const unsigned char* src = plane + (half ? kw1 * VP + c81 * 16 : kw0 * VP + c80 * 16);
+        bf16x8 xr[MT + 2];
+#pragma unroll
+        for (int r = 0; r < MT + 2; ++r) xr[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4c*>(src + r * (kLtW + 2) * VP));
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[kh], xr[t + kh], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) wcur[kh] = wnext[kh];
+      });
+    }
+  } else {
 #pragma unroll 1
   for (int kd = 0; kd < 3; ++kd) {
     const unsigned char* plane = lane_base + kd * (kLtH + 2) * (kLtW + 2) * VP;
@@ -341,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
       wf_cur = wf_next;
     });
   }
+  }
 
   // epilogue: D[i = cout][j = voxel]; lane: col j, rows (r&3) + 8*(r>>2) + 4*half
   const int od = d0 + wave, ow = w0 + col;
@@ -358,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
           u32x2c pk;
-          pk[0] = static_cast<unsigned>(f2bf(o[0])) | (static_cast<unsigned>(f2bf(o[1])) << 16);
-          pk[1] = static_cast<unsigned>(f2bf(o[2])) | (static_cast<unsigned>(f2bf(o[3])) << 16);
+          pk[0] = pack2_bf16(o[0], o[1]);
+          pk[1] = pack2_bf16(o[2], o[3]);
           *reinterpret_cast<u32x2c*>(yrow + co) = pk;
         }
       }
@@ -533,7 +583,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const unsigned short* __res
     u32x4c pk;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      pk[e] = static_cast<unsigned>(f2bf(acc[2 * e])) | (static_cast<unsigned>(f2bf(acc[2 * e + 1])) << 16);
+      pk[e] = pack2_bf16(acc[2 * e], acc[2 * e + 1]);
     stage[threadIdx.x * cpv + (c0 >> 3)] = pk;
   }
   __syncthreads();

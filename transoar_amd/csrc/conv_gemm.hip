@@ -47,10 +47,7 @@ __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<unsigned short>(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
 }
 // LDS-only barrier (see gemm.hip): does not drain the global loads in flight
 __device__ __forceinline__ void block_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

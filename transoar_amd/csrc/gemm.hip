@@ -41,10 +41,7 @@ __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
 }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<unsigned short>(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
 }
 __device__ __forceinline__ unsigned short f32_to_f16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));

@@ -33,16 +33,18 @@ __device__ __forceinline__ void unpack8(const u32x4n& r, float (&o)[8]) {
   }
 }
 __device__ __forceinline__ unsigned short f2bf_n(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<unsigned short>(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+__device__ __forceinline__ unsigned pack2_bf16_n(float a, float b) {        // one v_cvt_pk_bf16_f32 (round to nearest even)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ u32x4n pack8(const float (&o)[8]) {
   u32x4n r;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    r[i] = static_cast<unsigned>(f2bf_n(o[2 * i])) | (static_cast<unsigned>(f2bf_n(o[2 * i + 1])) << 16);
+    r[i] = pack2_bf16_n(o[2 * i], o[2 * i + 1]);
   return r;
 }
 

@@ -20,14 +20,13 @@ constexpr int kPersistentWaves = 256 * 4 * kWaves;   // backward: 4 workgroups p
 
 __device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
 }
-__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
-  return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {      // (bf16(b) << 16) | bf16(a) in one instruction
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
