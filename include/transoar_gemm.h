@@ -49,9 +49,19 @@ int transoar_gemm_k384_drop(const void* A, const void* B, const float* bias, voi
  *   transpose_out == 0: out (Na, 384) row-major;  != 0: out (384, Na) row-major (the case "384 is the layer's OUTPUT width").
  * The tokens are split into `chunks` = transoar_gemm_wgrad384_chunks(T, Na) ranges, one workgroup per range and column
  * tile; `part` holds chunks * Na * 384 floats of partial sums (device scratch), summed into `out` by a second kernel. */
+/* transoar_gemm_wgrad384_bias additionally sums one operand over the tokens (the layer's bias gradient, sum_t dY[t][:]),
+ * from the fragments the product has in registers anyway: bias_side 1 = A's Na columns, 2 = B's 384 columns, 0 = none;
+ * bias_part: chunks * (Na or 384) floats of scratch, bias_out: the sums (fp32). */
+int transoar_gemm_wgrad384_bias(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
+                                int chunks, float* bias_part, float* bias_out, int bias_side, void* hip_stream);
 int transoar_gemm_wgrad384_chunks(int T, int Na);
 int transoar_gemm_wgrad384(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
                            int chunks, void* hip_stream);
+
+/* The data gradient of the FFN's second layer with the gradient of dropout(relu(.)) in its epilogue
+ * (decoder_blocks.py:166-167 backwards): C (M, N) = gate > 0 ? (A (M, 384) . B (N, 384)^T) * scale : 0, gate (M, N) bf16 =
+ * the hidden tensor the forward saved (positive exactly where kept and active), scale = 1 / keep_prob. */
+int transoar_gemm_k384_gate(const void* A, const void* B, const void* gate, void* C, int M, int N, float scale, void* hip_stream);
 
 int transoar_gemm_abi_version(void);
 

@@ -160,3 +160,46 @@ def test_wgrad384_matches_fp32(t, n, k):
     old = conv_gemm.linear_wgrad(x, gy)
     assert (dw - old).abs().max().item() <= 2e-3 * ref.abs().max().item()
     assert torch.equal(dw, gemm.wgrad384(gy, x))          # deterministic: fixed chunking, no atomics
+    # the bias gradient from the same pass: column sums of gy out of the fragments the product holds in registers
+    dw2, db = gemm.wgrad384(gy, x, with_bias=True)
+    assert torch.equal(dw2, dw)
+    want = gy.double().sum(0)
+    assert (db.double() - want).abs().max().item() <= 1e-5 * gy.double().abs().sum(0).max().item()
+
+
+def test_fused_ffn_node_matches_fp32_chain():
+    """token_linear._FusedFFN (linear1 + ReLU + dropout + linear2 as one autograd node; the gate's gradient in the epilogue of
+    linear2's data-gradient GEMM, both bias gradients out of the weight-gradient passes) against the fp32 chain that uses the
+    kernel's own gate."""
+    from transoar_amd import token_linear as tl, tokens
+    g = torch.Generator(device="cuda").manual_seed(8)
+    m = 40001
+    x = torch.randn(m, 384, device="cuda", generator=g).to(torch.bfloat16)
+    lin1 = torch.nn.Linear(384, 1024).cuda()
+    lin2 = torch.nn.Linear(1024, 384).cuda()
+    drop = torch.nn.Dropout(0.1).train()
+    xg = x.clone().requires_grad_()
+    torch.manual_seed(13)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert tl.fused_ffn_usable(xg, lin1.weight, lin2.weight)
+        out = tl.fused_ffn(xg, lin1, lin2, drop)
+        torch.manual_seed(13)
+        hidden = tl.linear_relu_dropout(x, lin1.weight, lin1.bias, drop)          # same seed: the hidden tensor of the node
+    gy = torch.randn(out.shape, device="cuda", generator=g).to(torch.bfloat16)
+    out.backward(gy)
+    gate = (hidden.detach().float() > 0).float()
+    xr = x.float().requires_grad_()
+    w1 = lin1.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    w2 = lin2.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    b1 = lin1.bias.detach().clone().requires_grad_()
+    b2 = lin2.bias.detach().clone().requires_grad_()
+    h_ref = torch.nn.functional.linear(xr, w1, b1) * gate / 0.9
+    # the node's second layer reads the bf16-rounded hidden tensor
+    out_ref = torch.nn.functional.linear(h_ref + (hidden.detach().float() - h_ref).detach(), w2, b2)
+    out_ref.backward(gy.float())
+    rel = lambda a, c: float((a.detach().float() - c.detach()).abs().max() / c.detach().abs().max())
+    assert rel(hidden, h_ref) <= 2.0 ** -7
+    assert rel(out, out_ref) <= 2.0 ** -7
+    assert rel(xg.grad, xr.grad) <= 3e-2
+    assert rel(lin1.weight.grad, w1.grad) <= 3e-3 and rel(lin2.weight.grad, w2.grad) <= 3e-3
+    assert rel(lin1.bias.grad, b1.grad) <= 3e-3 and rel(lin2.bias.grad, b2.grad) <= 1e-4

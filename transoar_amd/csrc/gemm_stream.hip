@@ -44,10 +44,14 @@ __device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned seed) {
   return x;
 }
 
-template <bool RELU, bool DROP>
+// MASK: C = mask(y) ? (A B^T) * drop_scale : 0 with mask(y) = y > 0 read from `gate` (M, N) bf16 -- the gradient of
+// dropout(relu(.)) applied to the product that feeds it (the data gradient of the FFN's second layer): gate is the FFN's
+// saved hidden tensor, whose positive entries are exactly the kept, active ones.
+template <bool RELU, bool DROP, bool MASK = false>
 __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
-    unsigned short* __restrict__ C, int M, int N, const int* __restrict__ drop_seed, unsigned thr16, float drop_scale) {
+    unsigned short* __restrict__ C, int M, int N, const int* __restrict__ drop_seed, unsigned thr16, float drop_scale,
+    const unsigned short* __restrict__ gate = nullptr) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTile + kK384Waves * kOutBytes];
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
           if (bias != nullptr) b = kh ? bt[8 * qd + 4 + e] : bt[8 * qd + e];
           v[e] = c0[4 * qd + e] + c1[4 * qd + e] + b;
           if (RELU) v[e] = fmaxf(v[e], 0.f);
+          if (MASK) v[e] *= drop_scale;                 // scaled in fp32, rounded once; zeroed below where the gate is not positive
         }
         if (DROP) {                               // channels 32 t + 8 qd + 4 kh .. + 3 = two element pairs
           const unsigned p0 = pair_row + static_cast<unsigned>(16 * t + 4 * qd + 2 * kh);
@@ -128,8 +133,20 @@ __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + (lane >> 3), piece = lane & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(outb + row * kOutPitch + piece * 16);
-        if (m0w + row < M) *reinterpret_cast<u32x4*>(C + (m0w + row) * N + 32 * (t - 1) + 8 * piece) = v;
+        u32x4 v = *reinterpret_cast<const u32x4*>(outb + row * kOutPitch + piece * 16);
+        if (m0w + row < M) {
+          if (MASK) {
+            // bf16 > 0  <=>  sign bit clear and not zero (the gate holds no NaN: it is a ReLU output)
+            const u32x4 y = *reinterpret_cast<const u32x4*>(gate + (m0w + row) * N + 32 * (t - 1) + 8 * piece);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned lo = (y[e] & 0xffffu) - 1u < 0x7fffu ? 0x0000ffffu : 0u;
+              const unsigned hi = (y[e] >> 16) - 1u < 0x7fffu ? 0xffff0000u : 0u;
+              v[e] &= lo | hi;
+            }
+          }
+          *reinterpret_cast<u32x4*>(C + (m0w + row) * N + 32 * (t - 1) + 8 * piece) = v;
+        }
       }
     }
   }
@@ -298,7 +315,7 @@ __device__ __forceinline__ s16x8 tr_frag(const unsigned char* p0, const unsigned
 template <int NT, bool TR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad384_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ part,
-    int T, int Na, int chunk_len, int n_chunks, int n_tiles) {
+    int T, int Na, int chunk_len, int n_chunks, int n_tiles, float* __restrict__ bias_part, int bias_side) {
   using W = WgTile<NT>;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[W::kRing * W::kStage];
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -342,6 +359,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
 
+  // Column sums of one operand on the side (the layer's bias gradient: sum over the tokens of dY): the fragments are
+  // in registers anyway (sixteen VALU instructions per fragment, beside the matrix pipeline).  bias_side 1: A's columns (every workgroup
+  // its own 32 NT columns), 2: B's 384 columns (the workgroups of column tile 0, every wave its 96).
+  auto frag_sum = [&](s16x8 f, float acc) {
+    const u32x4 w = __builtin_bit_cast(u32x4, f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += bf16_lo(w[e]) + bf16_hi(w[e]);
+    return acc;
+  };
+  // (A's column tiles are shared out among the four waves, NT / 4 each: on one wave the sums cost 0.36 ms per step at
+  // the barrier of every stage)
+  const bool sum_a = bias_side == 1, sum_b = bias_side == 2 && tile == 0;
+  float asum[NT], bsum[3];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) asum[i] = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) bsum[jj] = 0.f;
   const unsigned a_soff0 = static_cast<unsigned>(t0) * lda_bytes + static_cast<unsigned>(n0) * 2u;
   auto issue = [&](int s) {
     unsigned char* stg = lds + (s % W::kRing) * W::kStage;
@@ -380,10 +414,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       s16x8 bf[3];
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) bf[jj] = tr_frag(bt + bbase[jj][0], bt + bbase[jj][1]);
+      if (sum_b) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) bsum[jj] = frag_sum(bf[jj], bsum[jj]);
+      }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int imm = 256 * (i >> 2);
         const s16x8 af = tr_frag(at + abase[i & 3] + imm, at + abase[i & 3] + imm + 4 * W::kPitch);
+        if (sum_a && i / (NT / 4) == wave) asum[i] = frag_sum(af, asum[i]);
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
           const s16x8 m_a = TR ? bf[jj] : af, m_b = TR ? af : bf[jj];
@@ -398,6 +437,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // per 24 MFMAs): those eight are inline assembly on VGPR accumulators.  The assembler statements are invisible to
   // the hazard recogniser, hence the wait states before the results are read.
   if (NT == 8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (sum_a) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      if (i / (NT / 4) != wave) continue;
+      const float v = asum[i] + other_half(asum[i]);
+      if (lane < 32) bias_part[static_cast<long>(chunk) * Na + n0 + 32 * i + lane] = v;
+    }
+  }
+  if (sum_b) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const float v = bsum[jj] + other_half(bsum[jj]);
+      if (lane < 32) bias_part[static_cast<long>(chunk) * kC + 96 * wave + 32 * jj + lane] = v;
+    }
+  }
   // ---- the chunk's partial: (Na, 384) row-major, or (384, Na) when TR
   float* out = part + static_cast<long>(chunk) * Na * kC;
 #pragma unroll
@@ -435,6 +489,14 @@ __global__ __launch_bounds__(256) void wgrad384_reduce(const float4* __restrict_
     }
     out[e] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad384_bias_reduce(const float* __restrict__ part, float* __restrict__ out, int cols, int n_chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int ch = 0; ch < n_chunks; ++ch) s += part[static_cast<long>(ch) * cols + c];
+  out[c] = s;
 }
 
 }  // namespace transoar
@@ -477,6 +539,19 @@ extern "C" int transoar_gemm_k384_drop(const void* A, const void* B, const float
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_gemm_k384_gate(const void* A, const void* B, const void* gate, void* C, int M, int N, float scale, void* hip_stream) {
+  if (!A || !B || !C || !gate) return TRANSOAR_GEMM_ERR_NULL;
+  if (M <= 0 || N <= 0 || (N & 63)) return TRANSOAR_GEMM_ERR_DIM;
+  if (static_cast<long>(N) * kRowBytes >= 0x7ffffff0L || static_cast<long>(M) * N * 2 >= (1L << 40)) return TRANSOAR_GEMM_ERR_DIM;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(gate)) & 15u)
+    return TRANSOAR_GEMM_ERR_ALIGN;
+  hipLaunchKernelGGL((gemm_k384_kernel<false, false, true>), dim3(static_cast<unsigned>((M + 32 * kK384Waves - 1) / (32 * kK384Waves))),
+                     dim3(64 * kK384Waves), 0, static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(A),
+                     static_cast<const unsigned short*>(B), nullptr, static_cast<unsigned short*>(C), M, N, nullptr, 0u, scale,
+                     static_cast<const unsigned short*>(gate));
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_gemm_n384(const void* A, const void* B, const float* bias, void* C, int M, int K, void* hip_stream) {
   if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
   if (M <= 0 || K <= 0 || (K & 31)) return TRANSOAR_GEMM_ERR_DIM;
@@ -497,9 +572,18 @@ extern "C" int transoar_gemm_wgrad384_chunks(int T, int Na) {
   return (T + len - 1) / len;
 }
 
+extern "C" int transoar_gemm_wgrad384_bias(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
+                                           int chunks, float* bias_part, float* bias_out, int bias_side, void* hip_stream);
+
 extern "C" int transoar_gemm_wgrad384(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
                                       int chunks, void* hip_stream) {
+  return transoar_gemm_wgrad384_bias(A, B, part, out, T, Na, transpose_out, chunks, nullptr, nullptr, 0, hip_stream);
+}
+
+extern "C" int transoar_gemm_wgrad384_bias(const void* A, const void* B, float* part, float* out, int T, int Na, int transpose_out,
+                                           int chunks, float* bias_part, float* bias_out, int bias_side, void* hip_stream) {
   if (!A || !B || !part || !out) return TRANSOAR_GEMM_ERR_NULL;
+  if (bias_side < 0 || bias_side > 2 || (bias_side != 0 && (!bias_part || !bias_out))) return bias_side < 0 || bias_side > 2 ? TRANSOAR_GEMM_ERR_DIM : TRANSOAR_GEMM_ERR_NULL;
   if (T <= 0 || Na <= 0 || (Na & 127) || chunks <= 0) return TRANSOAR_GEMM_ERR_DIM;
   if (static_cast<long>(T) * Na * 2 >= 0x7ffffff0L || static_cast<long>(T) * kRowBytes >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;   // 32-bit byte offsets
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15u)
@@ -515,13 +599,17 @@ extern "C" int transoar_gemm_wgrad384(const void* A, const void* B, float* part,
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
   if (wide) {
-    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<8, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
-    else hipLaunchKernelGGL((wgrad384_kernel<8, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<8, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles, bias_part, bias_side);
+    else hipLaunchKernelGGL((wgrad384_kernel<8, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles, bias_part, bias_side);
   } else {
-    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<4, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
-    else hipLaunchKernelGGL((wgrad384_kernel<4, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles);
+    if (transpose_out) hipLaunchKernelGGL((wgrad384_kernel<4, true>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles, bias_part, bias_side);
+    else hipLaunchKernelGGL((wgrad384_kernel<4, false>), grid, dim3(256), 0, st, a, b, part, T, Na, len, n_chunks, tiles, bias_part, bias_side);
   }
   const int n4 = Na * kC / 4;
   hipLaunchKernelGGL(wgrad384_reduce, dim3((n4 + 31) / 32), dim3(256), 0, st, reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), n4, n_chunks);
+  if (bias_side != 0) {
+    const int cols = bias_side == 1 ? Na : kC;
+    hipLaunchKernelGGL(wgrad384_bias_reduce, dim3((cols + 255) / 256), dim3(256), 0, st, bias_part, bias_out, cols, n_chunks);
+  }
   return static_cast<int>(hipGetLastError());
 }

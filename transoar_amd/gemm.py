@@ -28,12 +28,16 @@ def _load():
     lib.transoar_gemm_k384.argtypes = [p, p, p, p, i, i, i, p]
     lib.transoar_gemm_k384_drop.restype = i
     lib.transoar_gemm_k384_drop.argtypes = [p, p, p, p, i, i, i, p, ctypes.c_float, ctypes.c_float, p]
+    lib.transoar_gemm_k384_gate.restype = i
+    lib.transoar_gemm_k384_gate.argtypes = [p, p, p, p, i, i, ctypes.c_float, p]
     lib.transoar_gemm_n384.restype = i
     lib.transoar_gemm_n384.argtypes = [p, p, p, p, i, i, p]
     lib.transoar_gemm_wgrad384_chunks.restype = i
     lib.transoar_gemm_wgrad384_chunks.argtypes = [i, i]
     lib.transoar_gemm_wgrad384.restype = i
     lib.transoar_gemm_wgrad384.argtypes = [p, p, p, p, i, i, i, i, p]
+    lib.transoar_gemm_wgrad384_bias.restype = i
+    lib.transoar_gemm_wgrad384_bias.argtypes = [p, p, p, p, i, i, i, i, p, p, i, p]
     lib.transoar_gemm_abi_version.restype = i
     if lib.transoar_gemm_abi_version() != ABI_VERSION:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
@@ -142,20 +146,39 @@ def wgrad384_usable(gy, x):
     return WGRAD384 and other % 256 == 0 and 0 < other <= 1024 and gy.shape[0] >= 16384
 
 
-def wgrad384(gy, x):
-    """gy (T, n), x (T, k) -> dW (n, k) fp32 = gy^T x."""
+def wgrad384(gy, x, with_bias=False):
+    """gy (T, n), x (T, k) -> dW (n, k) fp32 = gy^T x;  with_bias: (dW, db) with db (n,) fp32 = gy.sum(0), summed from the
+    fragments of the same pass (the bias gradient of the layer: no second read of gy)."""
     t, n = gy.shape
     k = x.shape[1]
     if k == 384:
-        a, b, na, tr = gy, x, n, 0
+        a, b, na, tr, side = gy, x, n, 0, 1
     else:
-        a, b, na, tr = x, gy, k, 1
+        a, b, na, tr, side = x, gy, k, 1, 2
     chunks = lib.transoar_gemm_wgrad384_chunks(t, na)
     part = torch.empty((chunks, n, k), dtype=torch.float32, device=gy.device)
     out = torch.empty((n, k), dtype=torch.float32, device=gy.device)
+    bias_part = torch.empty((chunks, n), dtype=torch.float32, device=gy.device) if with_bias else None
+    db = torch.empty((n,), dtype=torch.float32, device=gy.device) if with_bias else None
     with torch.cuda.device(gy.device):
-        rc = lib.transoar_gemm_wgrad384(a.data_ptr(), b.data_ptr(), part.data_ptr(), out.data_ptr(), t, na, tr, chunks,
-                                        torch.cuda.current_stream().cuda_stream)
+        rc = lib.transoar_gemm_wgrad384_bias(a.data_ptr(), b.data_ptr(), part.data_ptr(), out.data_ptr(), t, na, tr, chunks,
+                                             bias_part.data_ptr() if with_bias else None, db.data_ptr() if with_bias else None,
+                                             side if with_bias else 0, torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("transoar_gemm_wgrad384 failed with code %d" % rc)
+    return (out, db) if with_bias else out
+
+
+def linear_gate(x, w, gate, scale):
+    """gate > 0 ? (x @ w.T) * scale : 0 in one kernel: x (M, 384), w (N, 384), gate (M, N) bf16 dense -- the data gradient of
+    the FFN's second layer with the gradient of dropout(relu(.)) in the GEMM's epilogue (gate = the saved hidden tensor)."""
+    if stream_kind(x, w) != "k384" or gate.shape != (x.shape[0], w.shape[0]) or gate.dtype != torch.bfloat16 or not gate.is_contiguous():
+        raise RuntimeError("linear_gate: needs the K = 384 streaming kernel (dense bf16 operands, >= 16384 rows) and a dense bf16 gate")
+    m, n = x.shape[0], w.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_gemm_k384_gate(x.data_ptr(), w.data_ptr(), gate.data_ptr(), out.data_ptr(), m, n, float(scale),
+                                         torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_k384_gate failed with code %d" % rc)
     return out

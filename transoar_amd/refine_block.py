@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .ms_deform_attn import MSDeformAttn
-from .token_linear import linear_relu_dropout, linear_relu_dropout_usable, token_linear
+from .token_linear import fused_ffn, fused_ffn_usable, linear_relu_dropout, linear_relu_dropout_usable, token_linear
 
 FUSED_FFN1 = os.environ.get("TRANSOAR_FUSED_FFN1", "1") != "0"      # linear1 + ReLU + dropout as one GEMM launch
 from . import tokens as fused_tokens
@@ -101,6 +101,12 @@ class DefAttnLayer(nn.Module):
         level_start) asks for the next layer's query.  -> (y32, y16, q16 or None)"""
         attn = self.self_attn(q16, reference_points, x16, spatial_shapes, level_start_index)
         y32, y16, _ = fused_tokens.add_layernorm(x, attn.contiguous(), self.norm1, dropout=self.dropout1)
+        if (self.activation is F.relu and fused_tokens.SEEDED_DROPOUT and FUSED_FFN1
+                and fused_ffn_usable(y16, self.linear1.weight, self.linear2.weight)):
+            # both layers as one autograd node: the gradient of ReLU + dropout rides in the epilogue of linear2's data-gradient
+            # GEMM, the bias gradients in the weight-gradient passes (token_linear._FusedFFN)
+            ffn = fused_ffn(y16, self.linear1, self.linear2, self.dropout2)
+            return fused_tokens.add_layernorm(y32, ffn.contiguous(), self.norm2, *pos_pack, dropout=self.dropout3)
         if (self.activation is F.relu and fused_tokens.SEEDED_DROPOUT and FUSED_FFN1
                 and linear_relu_dropout_usable(y16, self.linear1.weight)):
             # linear1 + bias + ReLU + dropout in ONE kernel (the K = 384 streaming GEMM's epilogue)

@@ -78,6 +78,15 @@ def weight_grad(gy, x):
     return out
 
 
+def weight_bias_grad(gy, x, want_w, want_b):
+    """(dW fp32 or None, db fp32 or None) of a linear layer over tokens; both from ONE pass over gy where the
+    token-streaming kernel applies (gemm.wgrad384: the column sums come out of the fragments it holds anyway), else the
+    weight gradient above and rows.colsum_any."""
+    if want_w and want_b and USE_HIP_WGRAD and gemm.wgrad384_usable(gy, x):
+        return gemm.wgrad384(gy, x, with_bias=True)
+    return (weight_grad(gy, x) if want_w else None), (rows.colsum_any(gy) if want_b else None)
+
+
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, force_hip=False, weight2=None):
@@ -117,10 +126,9 @@ class _TokenLinear(torch.autograd.Function):
                 wt = wb.t().contiguous()                   # (K, N): dX = dY . W as an NT product
                 gx = gemm.linear_nt(gy2, wt) if _hip_gemm(gy2, wt, ctx.force_hip) else torch.mm(gy2, wb)
                 gx = gx.view(xb.shape).to(ctx.in_dtype)
-            if ctx.needs_input_grad[1] or (ctx.split is not None and ctx.needs_input_grad[4]):
-                gw = weight_grad(gy2, xb.reshape(-1, xb.shape[-1]))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = rows.colsum_any(gy2)
+            gw, gb = weight_bias_grad(gy2, xb.reshape(-1, xb.shape[-1]),
+                                      ctx.needs_input_grad[1] or (ctx.split is not None and ctx.needs_input_grad[4]),
+                                      ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.split is not None and gw is not None:
             return gx, gw[:ctx.split], gb, None, gw[ctx.split:]
         return gx, gw, gb, None, None
@@ -158,10 +166,8 @@ class _LinearReluDropout(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 wt = wb.t().contiguous()
                 gx = gemm.linear_nt(gh, wt).view(xb.shape).to(ctx.in_dtype)
-            if ctx.needs_input_grad[1]:
-                gw = weight_grad(gh, xb.reshape(-1, xb.shape[-1]))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = rows.colsum_any(gh)
+            gw, gb = weight_bias_grad(gh, xb.reshape(-1, xb.shape[-1]), ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None, None
 
 
@@ -180,6 +186,62 @@ def linear_relu_dropout(x, weight, bias, dropout):
     active = dropout.training and dropout.p > 0.0
     seed = tokens.dropout_seed(x) if active else None
     return _LinearReluDropout.apply(x, weight, bias, seed, 1.0 - dropout.p if active else 1.0)
+
+
+class _FusedFFN(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) as ONE autograd node (decoder_blocks.py:166-167): forward = the fused first layer
+    above + the tiled GEMM; backward without a stand-alone element-wise pass --
+        gh   = hidden > 0 ? (gy W2) / keep : 0      one K = 384 GEMM, gate in its epilogue (gemm.linear_gate)
+        gW2, gb2 = gy^T hidden, sum gy               one token-streaming pass (gemm.wgrad384 with its column sums)
+        gx   = gh W1                                 tiled GEMM
+        gW1, gb1 = gh^T x, sum gh                    one token-streaming pass
+    (round 4 before this: relu_dropout_backward read gy_hidden and hidden and wrote gh, 1.4 GB per layer, and two column-sum
+    kernels re-read gy and gh)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, seed, keep_prob):
+        xb = x.to(torch.bfloat16)
+        w1b, w2b = shadow.bf16_or_cast(w1), shadow.bf16_or_cast(w2)
+        x2 = xb.reshape(-1, xb.shape[-1])
+        hidden = gemm.linear_relu_dropout(x2, w1b, b1, seed, keep_prob)
+        out = gemm.linear_nt(hidden, w2b, b2)
+        ctx.save_for_backward(xb, w1b, w2b, hidden)
+        ctx.in_dtype, ctx.scale = x.dtype, 1.0 / keep_prob
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        return out.view(*xb.shape[:-1], w2b.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, w1b, w2b, hidden = ctx.saved_tensors
+        gy2 = gy.to(torch.bfloat16).reshape(-1, gy.shape[-1]).contiguous()
+        x2 = xb.reshape(-1, xb.shape[-1])
+        need = ctx.needs_input_grad
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        with torch.autocast("cuda", enabled=False):
+            gh = gemm.linear_gate(gy2, w2b.t().contiguous(), hidden, ctx.scale)
+            gw2, gb2 = weight_bias_grad(gy2, hidden, need[3], ctx.has_b2 and need[4])
+            if need[0]:
+                gx = gemm.linear_nt(gh, w1b.t().contiguous()).view(xb.shape).to(ctx.in_dtype)
+            gw1, gb1 = weight_bias_grad(gh, x2, need[1], ctx.has_b1 and need[2])
+        return gx, gw1, gb1, gw2, gb2, None, None
+
+
+FUSED_FFN = os.environ.get("TRANSOAR_FUSED_FFN", "1") != "0"
+
+
+def fused_ffn_usable(x, w1, w2):
+    """Both layers of the refinement block's FFN as one node: what the fused first layer needs, 384 channels in and out,
+    a hidden width the K = 384 kernels take."""
+    return (FUSED_FFN and linear_relu_dropout_usable(x, w1) and w2.dtype == torch.float32 and w2.shape[0] == 384
+            and w2.shape[1] == w1.shape[0] and w1.shape[0] % 64 == 0)
+
+
+def fused_ffn(x, linear1, linear2, dropout):
+    """linear2(dropout(relu(linear1(x)))); `dropout`: the nn.Dropout module between the layers."""
+    from . import tokens
+    active = dropout.training and dropout.p > 0.0
+    seed = tokens.dropout_seed(x) if active else None
+    return _FusedFFN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, seed, 1.0 - dropout.p if active else 1.0)
 
 
 def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None, weight2=None):
