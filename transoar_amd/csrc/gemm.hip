@@ -67,12 +67,20 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (2 or 4), 2 along M
   constexpr int kStageBytes = kATileBytes + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][kStageBytes];      // [stage]: A tile, then B tile
-  const long t = xcd_contiguous(blockIdx.x, n_tiles);
-  if (t < 0) return;
-  const int tm = static_cast<int>(t / tiles_n), tn = static_cast<int>(t % tiles_n);
+  // Tiles of this workgroup: XCD x = block & 7 owns the contiguous eighth [x per, (x + 1) per) of the tiles (n fastest);
+  // its G = gridDim / 8 workgroups take tiles j, j + G, j + 2 G, ... of it.  With the full grid (G = per) that is one
+  // tile per workgroup; with the static K loops the host launches ~2 workgroups per CU (PERSIST) and the loads of the
+  // NEXT tile's first two K steps are issued under the last two K steps of this one: the 2-3 us of load latency at the
+  // head of every tile -- a third of a six-step K loop -- disappear behind the previous tile's MFMAs and epilogue.
+  constexpr bool PERSIST = KT_STATIC > 0 && (KT_STATIC % 2) == 0;
+  const long per = (n_tiles + 7) >> 3;
+  const long xend = min((static_cast<long>(blockIdx.x & 7) + 1) * per, n_tiles);
+  const long G = gridDim.x >> 3;
+  long t = static_cast<long>(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t >= xend) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;                  // wave's 64 x 64 part of the block tile
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0 = static_cast<int>(t / tiles_n) * BM, n0 = static_cast<int>(t % tiles_n) * BN;
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned short*>(A), 0, static_cast<int>(static_cast<long>(M) * lda * 2), 0x00020000);
@@ -86,20 +94,23 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + RPP i
   unsigned a_off[NA], b_off[NB];
   // a row past M / N gets an offset beyond any buffer (records < 2^31) that cannot wrap when the K offset is added
+  auto tile_offsets = [&](int tm0, int tn0, unsigned (&ao)[NA], unsigned (&bo)[NB]) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int r = s_row + RPP * i;
-    a_off[i] = (m0 + r) < M ? static_cast<unsigned>(m0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0x80000000u;
-  }
+    for (int i = 0; i < NA; ++i) {
+      const int r = s_row + RPP * i;
+      ao[i] = (tm0 + r) < M ? static_cast<unsigned>(tm0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0x80000000u;
+    }
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int r = s_row + RPP * i;
-    b_off[i] = (n0 + r) < N ? static_cast<unsigned>(n0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0x80000000u;
-  }
+    for (int i = 0; i < NB; ++i) {
+      const int r = s_row + RPP * i;
+      bo[i] = (tn0 + r) < N ? static_cast<unsigned>(tn0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0x80000000u;
+    }
+  };
+  tile_offsets(m0, n0, a_off, b_off);
   // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 waits in the other set
   // (one tile ahead leaves the HBM latency exposed: a K step is only ~500 cycles of MFMA per wave)
   u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  auto load_tile = [&](int kt, u32x4 (&ra_regs)[NA], u32x4 (&rb_regs)[NB]) {
+  auto load_tile = [&](int kt, const unsigned (&a_off)[NA], const unsigned (&b_off)[NB], u32x4 (&ra_regs)[NA], u32x4 (&rb_regs)[NB]) {
     // the K offset rides in the instruction's scalar offset: no per-lane address arithmetic in the loop
     const int kbyte = kt * BK * 2;
     if ((kt + 1) * BK <= K) {
@@ -129,25 +140,9 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   };
 
   f32x16 acc[2][2];          // [n tile][m tile] of the wave's quadrant, D = [n][m]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
   const int KT = (K + BK - 1) / BK;
   const int fr = lane & 31, kg = lane >> 5;
-  // the lane's 32 bias values (n = n0 + wn*64 + a*32 + 8q + 4kg + e), requested before the K loop: eight
-  // 16-byte loads in flight together instead of 64 dependent scalar loads in the epilogue
   float4 bv[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
-      bv[a][q] = (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-    }
   // fragment offsets inside an operand tile: loop invariant (row * 128 + swizzled piece * 16)
   int fa_off[4][2], fb_off[4][2];
 #pragma unroll
@@ -175,41 +170,73 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
         for (int b = 0; b < 2; ++b) acc[a][b] = mfma<F16>(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
     }
   };
+  if constexpr (PERSIST) {
+    load_tile(0, a_off, b_off, ra0, rb0);
+    load_tile(1, a_off, b_off, ra1, rb1);
+  }
+  bool first = true, has_next;
+  do {
+    if (!first) block_barrier();          // every wave is done with its output turn before the next tile's operands land in LDS
+    first = false;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // the lane's 32 bias values (n = n0 + wn*64 + a*32 + 8q + 4kg + e), requested before the K loop: eight
+    // 16-byte loads in flight together instead of 64 dependent scalar loads in the epilogue
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * kg;
+        bv[a][q] = (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+    const long t_next = t + G;
+    has_next = PERSIST && t_next < xend;
+    const int m0_next = static_cast<int>(t_next / tiles_n) * BM, n0_next = static_cast<int>(t_next % tiles_n) * BN;
+    unsigned a_nx[NA], b_nx[NB];
+    if constexpr (PERSIST) tile_offsets(m0_next, n0_next, a_nx, b_nx);
   if constexpr (KT_STATIC > 0) {
     // K known at compile time (the token shapes: 384 and 1024): the K loop is straight-line code, so the
     // compiler's wait counts are exact -- the ds_write of tile kt+1 waits for ITS loads only and leaves the
     // loads of tile kt+2 in flight (across the loop back-edge of the generic form it drains them)
-    load_tile(0, ra0, rb0);
-    if (KT_STATIC > 1) load_tile(1, ra1, rb1);
+    if constexpr (!PERSIST) {
+      load_tile(0, a_off, b_off, ra0, rb0);
+      if (KT_STATIC > 1) load_tile(1, a_off, b_off, ra1, rb1);
+    }
     store_tile(0, ra0, rb0);
     block_barrier();
 #pragma unroll
     for (int kt = 0; kt < KT_STATIC; ++kt) {
       if (kt & 1) {
-        if (kt + 2 < KT_STATIC) load_tile(kt + 2, ra1, rb1);
+        if (kt + 2 < KT_STATIC) load_tile(kt + 2, a_off, b_off, ra1, rb1);
+        else if (PERSIST && has_next) load_tile(kt + 2 - KT_STATIC, a_nx, b_nx, ra1, rb1);
         compute(1);
         if (kt + 1 < KT_STATIC) store_tile(0, ra0, rb0);
       } else {
-        if (kt + 2 < KT_STATIC) load_tile(kt + 2, ra0, rb0);
+        if (kt + 2 < KT_STATIC) load_tile(kt + 2, a_off, b_off, ra0, rb0);
+        else if (PERSIST && has_next) load_tile(kt + 2 - KT_STATIC, a_nx, b_nx, ra0, rb0);
         compute(0);
         if (kt + 1 < KT_STATIC) store_tile(1, ra1, rb1);
       }
       block_barrier();
     }
   } else {
-  load_tile(0, ra0, rb0);
-  if (KT > 1) load_tile(1, ra1, rb1);
+  load_tile(0, a_off, b_off, ra0, rb0);
+  if (KT > 1) load_tile(1, a_off, b_off, ra1, rb1);
   store_tile(0, ra0, rb0);
   block_barrier();
   for (int kt = 0; kt < KT; kt += 2) {
     // even step: LDS stage 0 holds tile kt; set 0 is free, set 1 holds tile kt+1
-    if (kt + 2 < KT) load_tile(kt + 2, ra0, rb0);
+    if (kt + 2 < KT) load_tile(kt + 2, a_off, b_off, ra0, rb0);
     compute(0);
     if (kt + 1 < KT) store_tile(1, ra1, rb1);
     block_barrier();
     if (kt + 1 >= KT) break;
     // odd step: stage 1 holds tile kt+1; set 1 is free, set 0 holds tile kt+2
-    if (kt + 3 < KT) load_tile(kt + 3, ra1, rb1);
+    if (kt + 3 < KT) load_tile(kt + 3, a_off, b_off, ra1, rb1);
     compute(1);
     if (kt + 2 < KT) store_tile(0, ra0, rb0);
     block_barrier();
@@ -282,6 +309,15 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
         }
     }
   }
+    // on to the workgroup's next tile (its first two K steps are already in the register sets)
+    if constexpr (PERSIST) {
+      t = t_next; m0 = m0_next; n0 = n0_next;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a_off[i] = a_nx[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) b_off[i] = b_nx[i];
+    }
+  } while (has_next);
 }
 
 template <bool F16, bool OUT_F32>
@@ -293,7 +329,15 @@ int launch(const void* A, const void* B, const float* bias, void* C, int M, int 
   const int BN = wide ? 256 : 128;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const long n_tiles = static_cast<long>(tiles_m) * tiles_n;
-  const dim3 grid(static_cast<unsigned>(((n_tiles + 7) / 8) * 8));
+  const int kts = K == 384 ? 6 : (K == 1024 ? 16 : 0);
+  // static K loops: persistent workgroups, two per CU (TRANSOAR_GEMM_PERSIST_WGS, 0 = one workgroup per tile)
+  static const long persist_wgs = [] {
+    const char* e = getenv("TRANSOAR_GEMM_PERSIST_WGS");
+    return e ? atol(e) : 512L;
+  }();
+  long per_xcd = (n_tiles + 7) / 8;
+  if (kts > 0 && persist_wgs >= 8 && per_xcd > persist_wgs / 8) per_xcd = persist_wgs / 8;
+  const dim3 grid(static_cast<unsigned>(per_xcd * 8));
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
 #define TRANSOAR_GEMM_LAUNCH(R, KTS)                                                                                        \
@@ -305,7 +349,6 @@ int launch(const void* A, const void* B, const float* bias, void* C, int M, int 
       hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS, 2>), grid, dim3(256), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
                          ldc, n_tiles, tiles_n);                                                                            \
   } while (0)
-  const int kts = K == 384 ? 6 : (K == 1024 ? 16 : 0);
   if (relu) {
     if (kts == 6) TRANSOAR_GEMM_LAUNCH(true, 6);
     else if (kts == 16) TRANSOAR_GEMM_LAUNCH(true, 16);
