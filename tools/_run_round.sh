@@ -16,6 +16,7 @@ python tools/bench_gemm.py > gpurun_out/${T}_gemm_bench.jsonl 2>/dev/null
 python tools/bench_convgemm.py > gpurun_out/${T}_conv_layers.jsonl 2>/dev/null; cut -c1-220 gpurun_out/${T}_conv_layers.jsonl | head -4
 TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --no-graph --steps 20 --warmup 5 > gpurun_out/${T}_bench_one_rank_rccl.json 2>/dev/null; python tools/_pr.py gpurun_out/${T}_bench_one_rank_rccl.json
 TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --graph --steps 20 --warmup 5 > gpurun_out/${T}_bench_one_rank_rccl_graph.json 2>/dev/null; python tools/_pr.py gpurun_out/${T}_bench_one_rank_rccl_graph.json
-python bench.py --swin --no-cpu-baseline > gpurun_out/${T}_bench_swin.json 2> /dev/null; python tools/_pr.py gpurun_out/${T}_bench_swin.json
+python bench.py --swin --no-refine --no-cpu-baseline > gpurun_out/${T}_bench_swin.json 2> /dev/null; python tools/_pr.py gpurun_out/${T}_bench_swin.json
+python bench.py --swin --no-cpu-baseline > gpurun_out/${T}_bench_swin_refine.json 2> /dev/null; python tools/_pr.py gpurun_out/${T}_bench_swin_refine.json
 python tools/bench_roi_attn.py > gpurun_out/${T}_roi_attn_bench.jsonl 2>/dev/null; tail -3 gpurun_out/${T}_roi_attn_bench.jsonl | cut -c1-220
 TRANSOAR_MSDA_DETERMINISTIC=1 python tools/bench_msda.py --iters 10 --dtypes bf16 --dists model > gpurun_out/${T}_msda_op_bench_deterministic.jsonl 2>/dev/null; cut -c1-200 gpurun_out/${T}_msda_op_bench_deterministic.jsonl

@@ -40,9 +40,10 @@ def _hip_gemm(x2, w, force=False):
     # K = N = 384 on the tiled kernel (round 2); every K = 384 or N = 384 product of >= 16 384 tokens on the streaming
     # kernels of csrc/gemm_stream.hip (round 4: the FFN shapes 384 -> 1024 -> 384 and their data gradients included)
     # ... and 1024 -> 384 (linear2 and linear1's data gradient) on the tiled kernel as well: 0.27 ms against hipBLASLt's
-    # 0.22, the price (0.1 ms per step) of a refinement block without a library GEMM
+    # 0.22, the price (0.1 ms per step) of a refinement block without a library GEMM.  Long K only: the Swin stages'
+    # 96 -> 384 products run the dynamic-K loop with two K steps and cost the Swin step 14 ms when they came here
     return (force or (x2.shape[1] == 384 and w.shape[0] == 384) or gemm.stream_kind(x2, w) is not None
-            or (OWN_FFN2 and w.shape[0] == 384 and x2.shape[0] >= 16384))
+            or (OWN_FFN2 and w.shape[0] == 384 and x2.shape[0] >= 16384 and x2.shape[1] >= 512 and x2.shape[1] % 128 == 0))
 
 
 def _chunks(tokens, n_out, n_in):
