@@ -157,6 +157,25 @@ int transoar_msda3d_backward(const void* value, const int64_t* spatial_shapes,
                              const int64_t* host_spatial_shapes, unsigned flags,
                              void* hip_stream);
 
+/*
+ * Backward with the sampling head's backward folded in (round 4).  Same inputs as transoar_msda3d_backward (the
+ * locations / weights the head produced in the forward, ops/modules/ms_deform_attn.py:114-128); instead of
+ * grad_sampling_loc / grad_attn_weight it writes grad_proj (N * Lq, 4 * M * L * P) bf16, the gradient of the stacked
+ * [sampling_offsets | attention_weights] projection: offsets bf16(bf16(grad_loc) / bf16(W | H | D)), logits
+ * a * (grad_attn - sum a * grad_attn) (softmax backward) -- the arithmetic of transoar_sampling_head_backward
+ * (include/transoar_tokens.h), without the 2 x 360 MB of fp32 gradients in between.
+ * Covers the matrix-core chain only: 16-bit value, fp32 locations, C = 64, P = 4, L = 4, queries = the pyramid's
+ * voxels, host shapes given; anything else returns TRANSOAR_ERR_MODE.  Workspace as for transoar_msda3d_backward.
+ */
+int transoar_msda3d_backward_proj(const void* value, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const void* sampling_loc,
+                                  const void* attn_weight, const void* grad_out,
+                                  void* grad_value, void* grad_proj, void* workspace,
+                                  size_t workspace_bytes, int N, int S, int M, int C, int L,
+                                  int Lq, int P, int value_dtype, int loc_dtype,
+                                  const int64_t* host_spatial_shapes, unsigned flags,
+                                  void* hip_stream);
+
 /* Scratch bytes transoar_msda3d_backward needs (0 if the arguments are
  * invalid).  Pure host arithmetic. */
 size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C,

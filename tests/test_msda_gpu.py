@@ -664,3 +664,69 @@ def test_deterministic_mode_follows_torch_switch_and_refuses_uncovered_forms(MSD
             MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go.float(), 64)
     finally:
         MSDA.deterministic = False
+
+
+# ---------------------------------------------------------------------------
+# the sampling head's backward folded into the query kernel (transoar_msda3d_backward_proj)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("geom", ["visceral", "amos"])
+def test_backward_proj_matches_backward_plus_head_kernel(MSDA, geom):
+    """grad_proj out of the operator's backward against the two-kernel chain it replaces (ms_deform_attn_backward, then
+    tokens' sampling_head_backward on its fp32 grad_loc / grad_attn): same arithmetic -- bf16(bf16(g) / bf16(size)) for the
+    offsets, a (g - sum a g) for the logits; the softmax dot is summed in another order, hence bf16 output rounding as the
+    bound.  grad_value is the same kernel chain: compared to the default's tolerance.  AMOS has 3 levels: not covered -> None."""
+    from transoar_amd import tokens
+    value, shapes, lsi, loc, attn = _full_size_case(geom, "model")
+    v = value.to(torch.bfloat16)
+    N, S, M, C = v.shape
+    L = shapes.shape[0]
+    go = torch.randn(N, S, M * C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(31)).to(torch.bfloat16)
+    # attention weights as the head produces them: a softmax over the L * P logits of a head
+    logits = torch.randn(N, S, M, L * 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(32))
+    attn = torch.softmax(logits, -1).view(N, S, M, L, 4).contiguous()
+    MSDA.flags = 0
+    res = MSDA.ms_deform_attn_backward_proj(v, shapes, lsi, loc, attn, go, 64)
+    if L != 4:
+        assert res is None
+        return
+    gv, gp = res
+    gv0, gl0, ga0 = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, attn, go, 64)
+    want = tokens.sampling_head_backward_raw(gl0.contiguous(), ga0.contiguous(), attn, shapes, M, L, 4, (N, S, 4 * M * L * 4))
+    assert gp.shape == want.shape and gp.dtype == torch.bfloat16
+    n_off = M * L * 4 * 3
+    assert torch.equal(gp[..., :n_off], want[..., :n_off])                       # offsets: the same three roundings
+    assert relerr(gp[..., n_off:], want[..., n_off:]) <= 2.0 ** -7
+    assert relerr(gv, gv0) <= TOL[torch.bfloat16]
+
+
+def test_module_head_gather_node_matches_two_node_path():
+    """MSDeformAttn in training mode: the one-node path (_HeadGather, gradient of the stacked projection straight out of the
+    operator) against the two-node path (sampling head node + MSDeformAttnFunction)."""
+    import transoar_amd.ms_deform_attn as mod
+    levels = _inputs.VISCERAL_LEVELS
+    S = sum(d * h * w for d, h, w in levels)
+    torch.manual_seed(3)
+    attn_mod = mod.MSDeformAttn(384, 4, 6, 4).cuda()
+    with torch.no_grad():
+        attn_mod.sampling_offsets.weight.normal_(0, 0.01)
+        attn_mod.attention_weights.weight.normal_(0, 0.05)
+    value, shapes, lsi, loc, _ = _inputs.model_like_inputs(5, 1, levels, device="cuda")
+    ref = loc[:, :, 0, :, 0, :].contiguous().clamp(0, 1)                 # (N, S, L, 3)
+    src = torch.randn(1, S, 384, device="cuda").to(torch.bfloat16)
+    query = (src.float() + 0.1 * torch.randn(1, S, 384, device="cuda")).to(torch.bfloat16)
+    gy = torch.randn(1, S, 384, device="cuda").to(torch.bfloat16)
+    grads = {}
+    for mode in (False, True):
+        mod.HEAD_GATHER = mode
+        attn_mod.zero_grad(set_to_none=True)
+        q = query.clone().requires_grad_()
+        s = src.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = attn_mod(q, ref, s, shapes, lsi)
+        out.backward(gy)
+        grads[mode] = {"out": out.detach().float(), "q": q.grad.float(), "s": s.grad.float(),
+                       **{n: p.grad.float().clone() for n, p in attn_mod.named_parameters()}}
+    mod.HEAD_GATHER = True
+    assert torch.equal(grads[True]["out"], grads[False]["out"])
+    for k in grads[False]:
+        assert relerr(grads[True][k], grads[False][k]) <= 2.0 ** -6, k

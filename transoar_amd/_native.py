@@ -43,6 +43,9 @@ def _load():
         lib.transoar_msda3d_backward.restype = c_int
         lib.transoar_msda3d_backward.argtypes = ([c_void_p] * 10 + [ctypes.c_size_t] + [c_int] * 9 +
                                                  [c_void_p, c_uint, c_void_p])
+        lib.transoar_msda3d_backward_proj.restype = c_int
+        lib.transoar_msda3d_backward_proj.argtypes = ([c_void_p] * 9 + [ctypes.c_size_t] + [c_int] * 9 +
+                                                      [c_void_p, c_uint, c_void_p])
         lib.transoar_msda3d_backward_workspace_bytes.restype = ctypes.c_size_t
         lib.transoar_msda3d_backward_workspace_bytes.argtypes = [c_int] * 9 + [c_uint]
         lib.transoar_msda3d_profile_enable.restype = None

@@ -383,9 +383,12 @@ template <typename VT, typename LT>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* grad_value,
                       void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes,
-                      const Dims& d, const int64_t* host_shapes, unsigned flags, hipStream_t st) {
+                      const Dims& d, const int64_t* host_shapes, unsigned flags, hipStream_t st, void* grad_proj = nullptr) {
   using A = typename Elem<VT>::acc;
   if (workspace_bytes < bwd_workspace_bytes<VT, LT>(d, flags)) return TRANSOAR_ERR_WORKSPACE;
+  // grad_proj: the sampling head's backward folded into the query kernel (transoar_msda3d_backward_proj): only the
+  // matrix-core chain writes it
+  if (grad_proj != nullptr && (sizeof(VT) != 2 || sizeof(LT) != 4 || vec_lpv(d, sizeof(VT), flags) < 0)) return TRANSOAR_ERR_MODE;
   const long n_items = static_cast<long>(d.N) * d.Lq * d.M;
   const BrickOrder q_order = make_order(host_shapes, d, d.Lq);
   const long q_units = order_units(q_order, d, d.Lq);
@@ -482,7 +485,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
         ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
         hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
                            v, lo, at, go, gl, ga, count + 1, reinterpret_cast<PointR16*>(ws + w.recs), nullptr,
-                           static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+                           static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d,
+                           static_cast<unsigned short*>(grad_proj));
       } else {
         // Deterministic order: every point's record goes to its canonical slot (upper half of the record region) with
         // the key (cell << 32 | slot); a stable radix sort of the keys (skipped points keep the all-ones key and end up
@@ -497,7 +501,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
           ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
           hipLaunchKernelGGL((msda3d_bwd_query_mma<VT, LT>), qgrid, dim3(64), 0, st,
                              v, lo, at, go, gl, ga, count + 1, slots, keys,
-                             static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d);
+                             static_cast<int>(cells_per_slab), d.S, d.M, d.L, vbytes, n_wave, order_d,
+                             static_cast<unsigned short*>(grad_proj));
         }
         ProfScope prof(TRANSOAR_PROF_CELL_FILL, st);
         int cell_bits = 1;
@@ -517,6 +522,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
     }
   }
   if (det_req && !det) return TRANSOAR_ERR_MODE;           // no silent fall-back to an order that depends on atomics
+  if (grad_proj != nullptr && !recs_done) return TRANSOAR_ERR_MODE;      // the other query kernels write grad_loc / grad_attn
   if constexpr (sizeof(VT) == 2) {
     if (!brick_done && q_order.enabled && fold_count && d.C == 64 && d.P == 4 && !(flags & TRANSOAR_MSDA3D_NO_BRICK)) {
       ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);
@@ -742,6 +748,32 @@ extern "C" int transoar_msda3d_backward(const void* value, const int64_t* spatia
                                         attn_weight, grad_out, grad_value, grad_sampling_loc,
                                         grad_attn_weight, workspace, workspace_bytes, d,
                                         host_spatial_shapes, flags, st)));
+}
+
+extern "C" int transoar_msda3d_backward_proj(const void* value, const int64_t* spatial_shapes,
+                                             const int64_t* level_start_index, const void* sampling_loc,
+                                             const void* attn_weight, const void* grad_out,
+                                             void* grad_value, void* grad_proj, void* workspace,
+                                             size_t workspace_bytes, int N, int S, int M, int C, int L,
+                                             int Lq, int P, int value_dtype, int loc_dtype,
+                                             const int64_t* host_spatial_shapes, unsigned flags,
+                                             void* hip_stream) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight ||
+      !grad_out || !grad_value || !grad_proj)
+    return TRANSOAR_ERR_NULL;
+  const Dims d{N, S, M, C, L, Lq, P};
+  const int rc = check_common(d, value_dtype, loc_dtype);
+  if (rc != TRANSOAR_OK) return rc;
+  if (loc_dtype != TRANSOAR_F32 || (value_dtype != TRANSOAR_BF16 && value_dtype != TRANSOAR_F16) || L * P != 16) return TRANSOAR_ERR_MODE;
+  if (misaligned(value) || misaligned(sampling_loc) || misaligned(attn_weight) ||
+      misaligned(grad_out) || misaligned(grad_value) || misaligned(grad_proj) || misaligned(workspace))
+    return TRANSOAR_ERR_ALIGN;
+  if (!workspace && workspace_bytes != 0) return TRANSOAR_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  TRANSOAR_DISPATCH(value_dtype, loc_dtype,
+                    (launch_bwd<VT, LT>(value, spatial_shapes, level_start_index, sampling_loc,
+                                        attn_weight, grad_out, grad_value, nullptr, nullptr, workspace, workspace_bytes, d,
+                                        host_spatial_shapes, flags, st, grad_proj)));
 }
 
 extern "C" size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C, int L, int Lq,

@@ -436,9 +436,12 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_mma(
 template <typename LT>
 __device__ __forceinline__ bool mma_level_points(const BrickOrder& order, int l, bool live, long item, int LP, int kg,
                                                  const LT* __restrict__ loc, const LT* __restrict__ attn,
-                                                 MmaPoint (&pt)[2], MmaBox& box) {
+                                                 MmaPoint (&pt)[2], MmaBox& box, float (&a_raw)[2]) {
+  // a_raw: the attention weights as stored, ALSO of skipped points (MmaPoint::a is zero there): the softmax backward of the
+  // folded sampling head needs them
   constexpr int P = 4;
   box = MmaBox{0, 0, 0, 0, 0, 0};
+  a_raw[0] = a_raw[1] = 0.f;
   const int D = order.D[l], H = order.H[l], W = order.W[l];
   int lo_d = 32767, lo_h = 32767, lo_w = 32767, hi_d = -1, hi_h = -1, hi_w = -1;
   float lx[2] = {0.f, 0.f}, ly[2] = {0.f, 0.f}, lz[2] = {0.f, 0.f}, la[2] = {0.f, 0.f};
@@ -459,6 +462,7 @@ __device__ __forceinline__ bool mma_level_points(const BrickOrder& order, int l,
       }
     }
   }
+  a_raw[0] = la[0]; a_raw[1] = la[1];
 #pragma unroll
   for (int pi = 0; pi < 2; ++pi) {
     MmaPoint g{0x3fffffff, 0.f, 0.f, 0.f, 0.f};
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     const VT* __restrict__ value, const LT* __restrict__ loc, const LT* __restrict__ attn,
     const VT* __restrict__ grad_out, LT* __restrict__ grad_loc, LT* __restrict__ grad_attn,
     int* __restrict__ cursor, PointR16* __restrict__ recs, unsigned long long* __restrict__ det_keys, int cells_per_slab,
-    int S, int M, int L, unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p) {
+    int S, int M, int L, unsigned value_bytes, long n_units, const BrickOrder* __restrict__ order_p,
+    unsigned short* __restrict__ grad_proj = nullptr) {
   const BrickOrder& order = *order_p;
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
@@ -537,11 +542,13 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
 
   MmaPoint pt[kMmaLevels][2];
   MmaBox box[kMmaLevels];
+  float a_in[kMmaLevels][2];          // attention weights as stored (the folded head's softmax backward)
   static_for<0, kMmaLevels>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     box[l] = MmaBox{0, 0, 0, 0, 0, 0};
+    a_in[l][0] = a_in[l][1] = 0.f;
     if (l >= L) return;
-    mma_level_points<LT>(order, l, live, item, LP, kg, loc, attn, pt[l], box[l]);
+    mma_level_points<LT>(order, l, live, item, LP, kg, loc, attn, pt[l], box[l], a_in[l]);
   });
 
   for (int i = lane; i < WR * 32 / 4; i += 64) reinterpret_cast<float4*>(gbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
@@ -809,6 +816,64 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     }
   });
 
+  if constexpr (sizeof(LT) == 4) {
+    if (grad_proj != nullptr) {
+      // ---- the sampling head's backward folded in (csrc/tokens.hip: sampling_head_bwd_p16; reference: the autograd of
+      // ops/modules/ms_deform_attn.py:114-128): instead of 64 fp32 gradients per (query, head) -- 360 MB written here and
+      // re-read by a second kernel -- the wave writes the gradient of the STACKED bf16 projection:
+      //   offsets  bf16( bf16(grad_loc) / bf16(W | H | D) )                          columns m 48 + l 12 + p 3 + k
+      //   logits   bf16( a (grad_attn - sum_{l,p} a grad_attn) )   (softmax backward)  columns 48 M + m 16 + l 4 + p
+      // A lane holds points 2 kg, 2 kg + 1 of every level; its partner (lane ^ 32) the other two.  The 32 queries' 128
+      // bytes each go through LDS and leave as 16-byte pieces of the projection rows.
+      float part = 0.f;
+      static_for<0, kMmaLevels>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if (l >= L) return;
+        part = fmaf(a_in[l][0], res_a[l][0], part);
+        part = fmaf(a_in[l][1], res_a[l][1], part);
+      });
+      const float dot = part + __shfl_xor(part, 32, 64);
+      unsigned* stage = reinterpret_cast<unsigned*>(vbuf);              // [query][32 dwords]: 24 of offsets, 8 of logits
+      int* tok = reinterpret_cast<int*>(vbuf + 32 * 128);               // projection row of the query, -1 = padding
+      auto bf = [](float x) -> unsigned { return static_cast<unsigned>(f32_to_bf16(x)); };
+      auto rnd = [](float x) -> float { return bf16_to_f32(f32_to_bf16(x)); };
+      static_for<0, kMmaLevels>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if (l >= L) return;
+        const float sz[3] = {rnd(static_cast<float>(order.W[l])), rnd(static_cast<float>(order.H[l])), rnd(static_cast<float>(order.D[l]))};
+        // x / size correctly rounded without the 10-instruction IEEE division: quotient estimate + one residual step (the
+        // divisor is a small integer, wave-uniform: its reciprocal is scalar work) -- msda3d_pcm.hpp's fused head does the same
+        const float rc[3] = {__builtin_amdgcn_rcpf(sz[0]), __builtin_amdgcn_rcpf(sz[1]), __builtin_amdgcn_rcpf(sz[2])};
+        unsigned o[6];
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float x = rnd(res_l[l][pi][k]);
+            const float q0 = x * rc[k];
+            o[3 * pi + k] = bf(__builtin_fmaf(__builtin_fmaf(-q0, sz[k], x), rc[k], q0));
+          }
+        unsigned* dst = stage + j * 32 + l * 6 + kg * 3;
+        dst[0] = o[0] | (o[1] << 16);
+        dst[1] = o[2] | (o[3] << 16);
+        dst[2] = o[4] | (o[5] << 16);
+        stage[j * 32 + 24 + l * 2 + kg] = bf(a_in[l][0] * (res_a[l][0] - dot)) | (bf(a_in[l][1] * (res_a[l][1] - dot)) << 16);
+      });
+      if (kg == 0) tok[j] = live ? static_cast<int>(b * S + s) : -1;
+      __syncthreads();          // one wave per workgroup: orders the LDS writes above before the reads below (also for the compiler)
+      const unsigned row_pieces = static_cast<unsigned>(M) * 8u;          // 16-byte pieces per projection row: 6 M of offsets, 2 M of logits
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int e = it * 64 + lane, q = e >> 3, pc = e & 7;
+        const int t = tok[q];
+        if (t < 0) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(vbuf + q * 128 + pc * 16);
+        const unsigned piece = pc < 6 ? static_cast<unsigned>(m) * 6u + pc : static_cast<unsigned>(M) * 6u + static_cast<unsigned>(m) * 2u + (pc - 6);
+        *reinterpret_cast<u32x4*>(grad_proj + (static_cast<long>(t) * row_pieces + piece) * 8) = v;
+      }
+      return;
+    }
+  }
   if (live) {
     static_for<0, kMmaLevels>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
@@ -873,7 +938,8 @@ __global__ __launch_bounds__(64) void msda3d_cell_count_mma(
     cell_start += (D + 1) * (H + 1) * (W + 1);
     MmaPoint pt[2];
     MmaBox bx;
-    if (!mma_level_points<LT>(order, l, live, item, LP, kg, loc, static_cast<const LT*>(nullptr), pt, bx)) return;
+    float a_unused[2];
+    if (!mma_level_points<LT>(order, l, live, item, LP, kg, loc, static_cast<const LT*>(nullptr), pt, bx, a_unused)) return;
     int* slab_count = count + static_cast<int>(b * M + m) * cells_per_slab + my_cell_start;
     const int CH = bx.TH + 1, CW = bx.TW + 1;
     const int ncells = (bx.TD + 1) * CH * CW;

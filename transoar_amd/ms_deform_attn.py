@@ -26,7 +26,8 @@ from torch.autograd.function import once_differentiable
 
 from . import msda as MSDA
 from .token_linear import token_linear
-from .tokens import sampling_head as _sampling_head, sampling_head_usable as _sampling_head_usable
+from .tokens import (sampling_head as _sampling_head, sampling_head_backward_raw as _head_bwd_raw,
+                     sampling_head_raw as _head_raw, sampling_head_usable as _sampling_head_usable)
 
 _debug_core = None
 
@@ -73,6 +74,38 @@ class MSDeformAttnFunction(Function):
         g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(
             value, shapes, starts, loc, attn, grad_output.contiguous(), ctx.im2col_step)
         return g_value, None, None, g_loc, g_attn, None
+
+
+class _HeadGather(Function):
+    """Sampling head + gather as ONE autograd node (round 4): forward = the head kernel and the gather, as before; the
+    backward asks the operator for the gradient of the stacked projection directly (transoar_msda3d_backward_proj: the
+    head's backward runs in the tail of the query kernel, the fp32 grad_loc / grad_attn never exist).  Forms that entry
+    does not cover take the two-kernel backward inside the same node."""
+
+    @staticmethod
+    def forward(ctx, value, proj, reference_points, shapes, level_start, m, lv, pt, im2col_step):
+        loc, attn = _head_raw(proj, reference_points, shapes, m, lv, pt)
+        out = MSDA.ms_deform_attn_forward(value, shapes, level_start, loc, attn, im2col_step)
+        ctx.save_for_backward(value, shapes, level_start, loc, attn)
+        ctx.head = (m, lv, pt, tuple(proj.shape), im2col_step)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, attn = ctx.saved_tensors
+        m, lv, pt, proj_shape, step = ctx.head
+        grad_output = grad_output.contiguous()
+        res = MSDA.ms_deform_attn_backward_proj(value, shapes, starts, loc, attn, grad_output, step)
+        if res is None:
+            g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, grad_output, step)
+            g_proj = _head_bwd_raw(g_loc.contiguous(), g_attn.contiguous(), attn, shapes, m, lv, pt, proj_shape)
+        else:
+            g_value, g_proj = res
+        return g_value, g_proj, None, None, None, None, None, None, None
+
+
+HEAD_GATHER = __import__("os").environ.get("TRANSOAR_HEAD_GATHER", "1") != "0"          # class switch (A/B and tests): the two-node path below is the reference's own structure
 
 
 def _axis_directions(n_heads):
@@ -155,6 +188,12 @@ class MSDeformAttn(nn.Module):
             sampled = MSDA.ms_deform_attn_forward_fused(value, input_spatial_shapes, proj, reference_points, strict=False)
             if sampled is not None:         # None: a form the fused kernel does not cover (e.g. level sizes > 1000)
                 return token_linear(sampled, self.output_proj.weight, self.output_proj.bias)
+        if (self.use_cuda and HEAD_GATHER and lv == 4 and pt == 4 and torch.is_grad_enabled()
+                and value.dtype in (torch.bfloat16, torch.float16)
+                and _sampling_head_usable(proj, reference_points, input_spatial_shapes, m, lv, pt)):
+            sampled = _HeadGather.apply(value, proj, reference_points, input_spatial_shapes, input_level_start_index,
+                                        m, lv, pt, self.im2col_step)
+            return token_linear(sampled, self.output_proj.weight, self.output_proj.bias)
         if self.use_cuda and _sampling_head_usable(proj, reference_points, input_spatial_shapes, m, lv, pt):
             locations, weights = _sampling_head(proj, reference_points, input_spatial_shapes, m, lv, pt)
         else:

@@ -202,3 +202,33 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         rc = run(flags)
     _native.check(rc, "transoar_msda3d_backward")
     return [grad_value, grad_loc.to(loc_in_dtype), grad_attn.to(attn_in_dtype)]
+
+
+def ms_deform_attn_backward_proj(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    """-> [grad_value, grad_proj] or None: the backward with the sampling head's backward folded into the query kernel
+    (transoar_msda3d_backward_proj): grad_proj (N, Lq, 4*M*L*P) bf16 is the gradient of the stacked [sampling_offsets |
+    attention_weights] projection.  None when the form is not covered (TRANSOAR_ERR_MODE): the caller then runs
+    ms_deform_attn_backward and the head's own backward kernel."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    N, S, M, C, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    _require(tuple(grad_output.shape) == (N, Lq, M * C) and grad_output.dtype == value.dtype,
+             "grad_output must be (N, Lq, M*C) with value's dtype")
+    if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32 or value.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    call_flags = flags | (DETERMINISTIC if (deterministic or torch.are_deterministic_algorithms_enabled()) else 0)
+    grad_value = torch.empty_like(value)
+    grad_proj = torch.empty((N, Lq, 4 * M * L * P), dtype=torch.bfloat16, device=value.device)
+    dims = (N, S, M, C, L, Lq, P, _DT[value.dtype], _DT[sampling_loc.dtype])
+    _keep, host_ptr = _shapes_on_host(spatial_shapes)
+    ws_bytes = _native.lib.transoar_msda3d_backward_workspace_bytes(*dims, call_flags)
+    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _native.lib.transoar_msda3d_backward_proj(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), grad_output.data_ptr(), grad_value.data_ptr(), grad_proj.data_ptr(),
+            workspace.data_ptr(), ws_bytes, *dims, host_ptr, call_flags, torch.cuda.current_stream().cuda_stream)
+    if rc == ERR_MODE:
+        return None
+    _native.check(rc, "transoar_msda3d_backward_proj")
+    return [grad_value, grad_proj]

@@ -298,6 +298,31 @@ class _SamplingHead(torch.autograd.Function):
         return g_proj, None, None, None, None, None
 
 
+def sampling_head_raw(proj, reference_points, shapes, m, lv, pt):
+    """The head's forward kernel without an autograd node: (locations, weights)."""
+    n, lq, _ = proj.shape
+    loc = torch.empty((n, lq, m, lv, pt, 3), dtype=torch.float32, device=proj.device)
+    attn = torch.empty((n, lq, m, lv, pt), dtype=torch.float32, device=proj.device)
+    with torch.cuda.device(proj.device):
+        rc = lib.transoar_sampling_head_forward(proj.data_ptr(), reference_points.data_ptr(), reference_points.shape[0] * lq,
+                                                shapes.data_ptr(), loc.data_ptr(), attn.data_ptr(), n * lq, m, lv, pt,
+                                                torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_sampling_head_forward failed with code %d" % rc)
+    return loc, attn
+
+
+def sampling_head_backward_raw(g_loc, g_attn, attn, shapes, m, lv, pt, proj_shape):
+    g_proj = torch.empty(proj_shape, dtype=torch.bfloat16, device=attn.device)
+    with torch.cuda.device(attn.device):
+        rc = lib.transoar_sampling_head_backward(g_loc.data_ptr(), g_attn.data_ptr(), attn.data_ptr(), shapes.data_ptr(),
+                                                 g_proj.data_ptr(), proj_shape[0] * proj_shape[1], m, lv, pt,
+                                                 torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_sampling_head_backward failed with code %d" % rc)
+    return g_proj
+
+
 def sampling_head_usable(proj, reference_points, shapes, m, lv, pt):
     return (proj.is_cuda and proj.dtype == torch.bfloat16 and proj.is_contiguous() and proj.dim() == 3
             and proj.shape[-1] == 4 * m * lv * pt and lv * pt <= 256
