@@ -68,6 +68,14 @@ int transoar_conv3d_k3_wgrad(const void* gyT, const void* xT3, float* dw, int N,
 int transoar_conv3d_k3_forward_c1(const void* x, const void* wk, const float* bias, void* y, int N, int D, int H,
                                   int W, int Cout, void* hip_stream);
 
+/* Forward of a full-resolution stride-1 layer (Cin = 1 | 8 | 16 | 24, Cout <= 32: the halo-tile kernel) that ALSO leaves
+ * the InstanceNorm statistics of its output behind: stat_part (rows, 2, 32) fp32 = per row of tiles (rows =
+ * transoar_conv3d_k3_stat_rows(...), 0 = the layer is not covered) the per-channel sum and sum of squares of the bf16
+ * outputs.  Cin == 1: x as for transoar_conv3d_k3_forward_c1 (wk (27, Cout, 8)), else as transoar_conv3d_k3_forward. */
+int transoar_conv3d_k3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int stride);
+int transoar_conv3d_k3_forward_stats(const void* x, const void* wk, const float* bias, void* y, float* stat_part,
+                                     int N, int D, int H, int W, int Cin, int Cout, void* hip_stream);
+
 /*
  * First layer, Cin == 1, stride 1: stencil.
  *   x (N, D, H, W) bf16 ; w (27, Cout) fp32 ; y (N, D, H, W, Cout) bf16 ; Cout % 8 == 0, Cout <= 64

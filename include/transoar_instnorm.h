@@ -34,6 +34,15 @@ int transoar_instnorm_relu_forward(const void* x, const float* gamma, const floa
                                    double* stats_ws, float* mean_rstd, int N, long V, int C,
                                    float eps, int relu, void* hip_stream);
 
+/* The same with the statistics already taken in the epilogue of the producing convolution (round 4;
+ * transoar_conv3d_k3_forward_stats in transoar_conv3d.h): stat_part (N * rows_per_sample, 2, 32) fp32 holds per row of
+ * conv tiles the sums and sums of squares of the bf16 outputs; a small kernel adds them in fp64 into stats_ws, then
+ * the apply pass of the entry above runs.  C <= 32.  (encoder_blocks.py:28-36: Conv3d -> InstanceNorm3d -> ReLU) */
+int transoar_instnorm_relu_forward_parts(const void* x, const float* gamma, const float* beta, void* y,
+                                         const float* stat_part, int rows_per_sample, double* stats_ws,
+                                         float* mean_rstd, int N, long V, int C, float eps, int relu,
+                                         void* hip_stream);
+
 /* dx of the above; red_ws ends up holding, per (n,c), {sum g, sum g*xhat} with
  * g = dy * [relu active]: dbeta_c = sum_n red[n][c][0], dgamma_c = sum_n red[n][c][1]. */
 int transoar_instnorm_relu_backward(const void* x, const void* dy, const float* gamma,

@@ -65,3 +65,44 @@ def test_instnorm_relu_flagship_stem_shape():
     # per-channel sums over 13e6 voxels: fp32 accumulation order differs
     assert err(gamma.grad, gr.grad) <= 1e-2
     assert err(beta.grad, br.grad) <= 1e-2
+
+
+@pytest.mark.parametrize("cin,shape", [(1, (2, 32, 48, 64)), (24, (2, 30, 34, 72)), (24, (1, 41, 44, 40)), (8, (1, 32, 48, 64))])
+def test_statistics_from_the_conv_epilogue(cin, shape):
+    """conv3d_k3_lds<.., STATS>: the per-channel sum / sum of squares of the convolution's bf16 output, taken from the
+    accumulators, against sums over the stored output; and InstanceNorm + ReLU fed with them against the kernel that makes
+    its own pass (same apply pass: only the statistics' summation order differs), forward and backward."""
+    from transoar_amd import conv3d, instnorm
+    n, d, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(cin + d)
+    conv = conv3d.Conv3dK3(cin, 24, 3, padding=1, bias=False).cuda()
+    x = torch.randn(n, cin, d, h, w, device="cuda", generator=g).to(torch.bfloat16)
+    if cin > 1:
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+    if cin > 1:
+        x.requires_grad_()                    # (the one-channel stem's input is the volume: no data gradient exists for it)
+    gamma = (torch.rand(24, device="cuda", generator=g) + 0.5).requires_grad_()
+    beta = torch.randn(24, device="cuda", generator=g).requires_grad_()
+    y, part = conv.forward_with_stats(x)
+    assert part is not None and part.shape[1:] == (2, 32)
+    y_plain = conv(x)
+    assert torch.equal(y, y_plain)
+    yf = y.detach().float()
+    rows = part.shape[0] // n
+    got = part.view(n, rows, 2, 32).double().sum(1)
+    want_sum = yf.double().sum((2, 3, 4))
+    want_sq = (yf.double() ** 2).sum((2, 3, 4))
+    scale = (yf.double().abs()).sum((2, 3, 4))
+    assert ((got[:, 0, :24] - want_sum).abs() <= 2e-6 * scale).all()
+    assert ((got[:, 1, :24] - want_sq).abs() <= 2e-6 * want_sq).all()
+    assert float(got[:, :, 24:].abs().max()) == 0.0
+    out = instnorm.instance_norm_relu(y, gamma, beta, 1e-5, True, part)
+    ref = instnorm.instance_norm_relu(y_plain, gamma, beta, 1e-5, True)
+    assert float((out.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+    assert float((out != ref).float().mean()) < 1e-3           # same apply pass: an entry moves only where a statistic's last bits flip a rounding
+    go = torch.randn(out.shape, device="cuda", generator=g).to(torch.bfloat16)
+    wrt = ((x,) if cin > 1 else ()) + (gamma, beta, conv.weight)
+    grads = torch.autograd.grad(out, wrt, go, retain_graph=True)
+    grads_ref = torch.autograd.grad(ref, wrt, go)
+    for a, b in zip(grads, grads_ref):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-2 * float(b.float().abs().max())

@@ -43,18 +43,28 @@ class EncoderCnnBlock(nn.Module):
 
     fused_norm = True      # class switch (A/B against MIOpen's batch-norm kernels)
 
-    def _norm_relu(self, x, norm):
+    def _norm_relu(self, x, norm, part=None):
         if (EncoderCnnBlock.fused_norm and self._affine and x.dtype == torch.bfloat16
                 and instnorm.supported(x, norm.num_features)):
-            return instnorm.instance_norm_relu(x, norm.weight, norm.bias, norm.eps, relu=True)
+            return instnorm.instance_norm_relu(x, norm.weight, norm.bias, norm.eps, relu=True, part=part)
         return torch.relu_(norm(x))
+
+    def _conv_norm_relu(self, conv, norm, x):
+        # the statistics of the InstanceNorm come out of the convolution's epilogue where its kernel offers them (the
+        # full-resolution layers of stage 0: one pass over the 629-MB map less per layer)
+        if (EncoderCnnBlock.fused_norm and self._affine and isinstance(conv, Conv3dK3) and norm.num_features <= 32):
+            y, part = conv.forward_with_stats(x)
+            if part is not None and not (y.dtype == torch.bfloat16 and instnorm.supported(y, norm.num_features)):
+                part = None
+            return self._norm_relu(y, norm, part)
+        return self._norm_relu(conv(x), norm)
 
     def forward(self, x):
         if not x.is_cuda:
             return self._block(x)
         blk = self._block
-        x = self._norm_relu(blk[0](x), blk[1])
-        return self._norm_relu(blk[3](x), blk[4])
+        x = self._conv_norm_relu(blk[0], blk[1], x)
+        return self._conv_norm_relu(blk[3], blk[4], x)
 
 
 class Encoder(nn.Module):

@@ -42,6 +42,10 @@ def _load():
     lib.transoar_conv3d_c1_wgrad.argtypes = [p, p, p, i] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_wgrad_tr.restype = i
     lib.transoar_conv3d_c1_wgrad_tr.argtypes = [p, p, p, i] + [i] * 5 + [p]
+    lib.transoar_conv3d_k3_stat_rows.restype = i
+    lib.transoar_conv3d_k3_stat_rows.argtypes = [i] * 7
+    lib.transoar_conv3d_k3_forward_stats.restype = i
+    lib.transoar_conv3d_k3_forward_stats.argtypes = [p, p, p, p, p] + [i] * 6 + [p]
     lib.transoar_conv3d_k3_forward_c1.restype = i
     lib.transoar_conv3d_k3_forward_c1.argtypes = [p, p, p, p] + [i] * 5 + [p]
     lib.transoar_conv3d_c1_forward.restype = i
@@ -153,6 +157,27 @@ def conv3d_k3_forward_c1(x, wk, bias):
     return y.permute(0, 4, 1, 2, 3)
 
 
+def conv3d_k3_forward_stats(x, wk, bias):
+    """The halo-tile forward with the InstanceNorm statistics of its output in the epilogue: x (N, Cin, D, H, W) NDHWC bf16
+    (Cin = 1: (N, 1, D, H, W) contiguous, wk (27, Cout, 8)) -> (y NDHWC bf16, part (rows, 2, 32) fp32) or None when the
+    layer is not one of the halo-tile kernel's."""
+    n, ci, d, h, w = x.shape
+    co = wk.shape[1]
+    rows = lib.transoar_conv3d_k3_stat_rows(n, d, h, w, ci, co, 1)
+    if rows == 0:
+        return None
+    if ci == 1:
+        y = torch.empty((n, d, h, w, co), dtype=torch.bfloat16, device=x.device).permute(0, 4, 1, 2, 3)
+    else:
+        y = torch.empty((n, co, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=CL3D)
+    part = torch.empty((rows, 2, 32), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_conv3d_k3_forward_stats(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                    y.data_ptr(), part.data_ptr(), n, d, h, w, ci, co, _stream()),
+               "transoar_conv3d_k3_forward_stats")
+    return y, part
+
+
 def wgrad_operands(x, gy, stride):
     """Channels-first operands of the weight-gradient GEMM (K = voxels):
     gyT (Cout,N,Do,Ho,Wo) and xT3 (3,Cin,N,D,H,Wo), the three W-shifted (and for
@@ -231,12 +256,25 @@ def c1_wgrad_supported(x, gy):
 
 class _Conv3dK3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, packs=None):
+    def forward(ctx, x, weight, bias, stride, packs=None, want_stats=False):
         # one input channel: NDHWC == NCDHW; keep canonical strides so nothing downstream
         # (MIOpen's weight gradient) mistakes it for a channels-last problem
         xb = x.to(torch.bfloat16).contiguous() if x.shape[1] == 1 else _as_ndhwc(x)
         ci = xb.shape[1]
         wkt = None
+        if want_stats:
+            # the caller normalises the output next (EncoderCnnBlock): statistics in the conv epilogue where the halo-tile
+            # kernel takes the layer; returns (y, part) -- part None when it does not
+            res = None
+            if stride == 1 and (ci == 1 or not _use_gemm(ci, weight.shape[0], stride)):
+                wk = _pack_taps(F.pad(weight, (0, 0, 0, 0, 0, 0, 0, 7)) if ci == 1 else weight)
+                res = conv3d_k3_forward_stats(xb, wk, bias.float() if bias is not None else None)
+            if res is not None:
+                ctx.save_for_backward(xb, weight, None)
+                ctx.stride, ctx.has_bias, ctx.two = stride, bias is not None, True
+                ctx.mark_non_differentiable(res[1])
+                return res
+        ctx.two = want_stats
         if ci == 1:
             # one input channel: through the MFMA implicit GEMM with the channel axis zero-padded to 8
             # (K = 27 taps x 8); the scalar stencil kernel (transoar_conv3d_c1_forward) is VALU-bound at a
@@ -265,10 +303,10 @@ class _Conv3dK3(torch.autograd.Function):
             y = conv3d_k3_forward(xb, _pack_taps(weight), bias.float() if bias is not None else None, stride)
         ctx.save_for_backward(xb, weight, wkt)
         ctx.stride, ctx.has_bias = stride, bias is not None
-        return y
+        return (y, None) if want_stats else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         # Every gradient runs on a hand-written kernel; there is no stock (MIOpen) branch.  A problem no kernel
         # covers raises: falling through to MIOpen's untuned 3-D bf16 kernels once cost a 1.7-second step.
         xb, weight, wkt = ctx.saved_tensors
@@ -296,7 +334,7 @@ class _Conv3dK3(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g2 = gyb.permute(0, 2, 3, 4, 1).reshape(-1, gyb.shape[1])        # channels-last: a view, rows = voxels
             gb = _rows.colsum(g2) if _rows.colsum_usable(g2) else gyb.float().sum(dim=(0, 2, 3, 4))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 def _use_gemm(cin, cout, stride):
@@ -343,3 +381,16 @@ class Conv3dK3(nn.Conv3d):
         if x.is_cuda and not Conv3dK3.ndhwc_everywhere:
             x = to_ncdhw(x)
         return super().forward(x)
+
+    stats_in_epilogue = os.environ.get("TRANSOAR_CONV_STATS", "1") != "0"
+
+    def forward_with_stats(self, x):
+        """-> (y, part): forward(x) and, where the halo-tile kernel takes the layer (the full-resolution stride-1 layers of
+        stage 0), the InstanceNorm statistics of y as per-workgroup partial sums (instnorm.instance_norm_relu's `part`);
+        part is None everywhere else."""
+        amp = torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        xb = x.to(torch.bfloat16) if (amp and x.dtype != torch.bfloat16) else x
+        if (Conv3dK3.enabled and Conv3dK3.stats_in_epilogue and self.stride == (1, 1, 1) and self.out_channels <= 32
+                and hip_conv_supported(xb, self)):
+            return _Conv3dK3.apply(xb, self.weight, self.bias, 1, None, True)
+        return self.forward(x), None

@@ -231,13 +231,19 @@ __device__ __forceinline__ void static_for_conv(F&& f) {
 constexpr int kLtD = 4, kLtH = 4, kLtW = 32;
 constexpr int kLtHaloVox = (kLtD + 2) * (kLtH + 2) * (kLtW + 2);
 
-template <int CPT, bool C1 = false>      // C1: the input has ONE channel (2 bytes per voxel), zero-extended to 8 while staging
+// STATS (round 4): the per-channel sum and sum of squares of the (bf16-rounded) outputs -- what the InstanceNorm that
+// follows needs -- are taken from the accumulators in the epilogue instead of by a second pass over the 629-MB map:
+// per tile a lane sums its 4 rows, a reduce-scatter over the 32 lanes of a wave half (one channel quad at a time; xor 16: sums | squares,
+// xor 8 and 4: the quad's channels, two butterfly steps) leaves one running value per quad and lane; at the end of the workgroup's row of
+// tiles they go through LDS into stat_part[row of tiles][sum | sumsq][32 channels] (fp32, <= 4 096 voxels each; a second
+// kernel adds the rows in fp64: instnorm.hip).
+template <int CPT, bool C1 = false, bool STATS = false>      // C1: the input has ONE channel (2 bytes per voxel), zero-extended to 8 while staging
 __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ wk,
                                                         const float* __restrict__ bias,
                                                         unsigned short* __restrict__ y, ConvGeom g, int tiles_d,
                                                         int tiles_h, int tiles_w, long n_tiles, unsigned x_bytes,
-                                                        unsigned w_bytes) {
+                                                        unsigned w_bytes, float* __restrict__ stat_part = nullptr) {
   constexpr int VP = CPT * 16;                    // bytes per voxel (Cin = 8 * CPT channels)
   constexpr int MT = kLtH;
   __shared__ __attribute__((aligned(16))) unsigned char halo[kLtHaloVox * VP];
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
       }
     }
   };
+  float srun[4] = {0.f, 0.f, 0.f, 0.f};     // STATS: this lane's running value per channel quad (see the epilogue)
   fetch(0);
   for (int tw = 0; tw < tiles_w; ++tw) {
   const int w0 = tw * kLtW;
@@ -415,7 +422,97 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_lds(const unsigned short* __
       }
     }
   }
+  if (STATS) {
+    // One channel quad (gq) at a time -- eight temporaries instead of thirty-two beside the 60 registers of the prefetched
+    // halo: the lane's sums and squares over the tile's 4 rows (the values as stored: rounded to bf16 once more here), then
+    // a reduce-scatter over the 32 lanes of the half (col = voxel): xor 16 keeps sums | squares, two mirror steps halve
+    // the four channels down to one, two butterfly steps inside the quad finish it: lane (b4, b3, b2) holds {sum | sumsq by b4} of channel
+    // 8 gq + 4 half + 2 b3 + b2 and adds it to its running value of that quad.
+    const bool vox_ok = od < g.D && ow < g.W;
+    const bool tile_full = od < g.D && h0 + MT <= g.H && w0 + kLtW <= g.W;          // wave-uniform
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (8 * gq >= g.Cout) continue;                 // (wave-uniform; the quad of the other half may still be live)
+      const int co = 8 * gq + 4 * half;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tile_full && 8 * gq + 8 <= g.Cout) {          // the common case, straight-line: every voxel and both halves' channels live
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
+          const unsigned p0 = pack2_bf16(o[0], o[1]), p1 = pack2_bf16(o[2], o[3]);
+          const float r[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16),
+                              __uint_as_float(p1 & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s4[e] += r[e];
+            q4[e] = __builtin_fmaf(r[e], r[e], q4[e]);
+          }
+        }
+      } else if (vox_ok && co < g.Cout) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          if (h0 + t >= g.H) continue;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * gq + e] + (bias ? bias[co + e] : 0.f);
+          const unsigned p0 = pack2_bf16(o[0], o[1]), p1 = pack2_bf16(o[2], o[3]);
+          const float r[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16),
+                              __uint_as_float(p1 & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s4[e] += r[e];
+            q4[e] += r[e] * r[e];
+          }
+        }
+      }
+      float v4[4];
+      {
+        const bool up = (col & 16) != 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = (up ? q4[e] : s4[e]) + __shfl_xor(up ? s4[e] : q4[e], 16, 64);
+      }
+      // inside a row of 16 lanes the partners are the DPP mirrors (lane i <-> 15 - i has the other bit 3, i <-> 7 - i inside
+      // eight lanes the other bit 2): VALU moves instead of ds_bpermute round trips (36 of them per tile cost the 24 -> 24
+      // layer 0.17 ms)
+#define TRANSOAR_DPP_F(v, CTRL) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true))
+      float v2[2];
+      {
+        const bool up = (col & 8) != 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float give = up ? v4[e] : v4[2 + e];
+          v2[e] = (up ? v4[2 + e] : v4[e]) + TRANSOAR_DPP_F(give, 0x140);          // row_mirror
+        }
+      }
+      float v1;
+      {
+        const bool up = (col & 4) != 0;
+        const float give = up ? v2[0] : v2[1];
+        v1 = (up ? v2[1] : v2[0]) + TRANSOAR_DPP_F(give, 0x141);                    // row_half_mirror
+      }
+      v1 += TRANSOAR_DPP_F(v1, 0x4E);                                               // quad_perm [2,3,0,1]
+      v1 += TRANSOAR_DPP_F(v1, 0xB1);                                               // quad_perm [1,0,3,2]
+#undef TRANSOAR_DPP_F
+      srun[gq] += v1;
+    }
+  }
   __syncthreads();          // every wave is done with this halo before the next one lands
+  }
+  if (STATS) {
+    // lane (half, b4, b3, b2): srun[gq] = {sum | sumsq by b4} of output channel 8 gq + 4 half + 2 b3 + b2; the four waves
+    // (depths) meet in LDS
+    float* red = reinterpret_cast<float*>(halo);              // [wave][which][32 channels]
+    if ((col & 3) == 0) {
+      const int which = (col >> 4) & 1;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        red[(wave * 2 + which) * 32 + 8 * gq + 4 * half + 2 * ((col >> 3) & 1) + ((col >> 2) & 1)] = srun[gq];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+      stat_part[trow * 64 + threadIdx.x] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
   }
 }
 
@@ -905,6 +1002,43 @@ extern "C" int transoar_conv3d_k3_forward_c1(const void* x, const void* wk, cons
                      static_cast<hipStream_t>(hip_stream), static_cast<const unsigned short*>(x),
                      static_cast<const unsigned short*>(wk), bias, static_cast<unsigned short*>(y), g, tiles_d, tiles_h,
                      tiles_w, n_rows, static_cast<unsigned>(x_bytes), static_cast<unsigned>(w_bytes));
+  return static_cast<int>(hipGetLastError());
+}
+
+// ---- forward with the InstanceNorm statistics in the epilogue (conv3d_k3_lds<.., STATS = true>)
+extern "C" int transoar_conv3d_k3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int stride) {
+  static const bool no_lds = getenv("TRANSOAR_CONV_NO_LDS") != nullptr;
+  if (no_lds || stride != 1 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || (Cout & 3)) return 0;
+  if (!(Cin == 1 || Cin == 8 || Cin == 16 || Cin == 24) || static_cast<long>(D) * H * W < (1L << 16)) return 0;
+  const long rows = static_cast<long>(N) * ((D + kLtD - 1) / kLtD) * ((H + kLtH - 1) / kLtH);
+  return rows < (1L << 30) ? static_cast<int>(rows) : 0;
+}
+
+extern "C" int transoar_conv3d_k3_forward_stats(const void* x, const void* wk, const float* bias, void* y, float* stat_part,
+                                                int N, int D, int H, int W, int Cin, int Cout, void* hip_stream) {
+  if (!x || !wk || !y || !stat_part) return TRANSOAR_CONV_ERR_NULL;
+  if (transoar_conv3d_k3_stat_rows(N, D, H, W, Cin, Cout, 1) == 0) return TRANSOAR_CONV_ERR_DIM;
+  ConvGeom g;
+  g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin == 1 ? 8 : Cin; g.Cout = Cout; g.CinP = g.Cin; g.stride = 1;
+  g.Do = D; g.Ho = H; g.Wo = W;
+  const long x_bytes = static_cast<long>(N) * D * H * W * Cin * 2;
+  const long w_bytes = 27L * Cout * g.CinP * 2;
+  if (!fits32(x_bytes) || !fits32(w_bytes) || static_cast<long>(N) * D * H * W >= (1L << 31)) return TRANSOAR_CONV_ERR_DIM;
+  const int tiles_d = (D + kLtD - 1) / kLtD, tiles_h = (H + kLtH - 1) / kLtH, tiles_w = (W + kLtW - 1) / kLtW;
+  const long n_rows = static_cast<long>(N) * tiles_d * tiles_h;
+  const dim3 grid(static_cast<unsigned>(((n_rows + 7) / 8) * 8));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  auto xp = static_cast<const unsigned short*>(x);
+  auto wp = static_cast<const unsigned short*>(wk);
+  auto yp = static_cast<unsigned short*>(y);
+#define TRANSOAR_CONV_LDS_STATS(CPTV, C1V)                                                                             \
+  hipLaunchKernelGGL((conv3d_k3_lds<CPTV, C1V, true>), grid, dim3(256), 0, st, xp, wp, bias, yp, g, tiles_d, tiles_h, tiles_w, \
+                     n_rows, static_cast<unsigned>(x_bytes), static_cast<unsigned>(w_bytes), stat_part)
+  if (Cin == 1) TRANSOAR_CONV_LDS_STATS(1, true);
+  else if (Cin == 8) TRANSOAR_CONV_LDS_STATS(1, false);
+  else if (Cin == 16) TRANSOAR_CONV_LDS_STATS(2, false);
+  else TRANSOAR_CONV_LDS_STATS(3, false);
+#undef TRANSOAR_CONV_LDS_STATS
   return static_cast<int>(hipGetLastError());
 }
 

@@ -108,6 +108,24 @@ __global__ __launch_bounds__(kINThreads) void instnorm_stats(const unsigned shor
   block_reduce_to_global<2>(acc, chunks, stats + static_cast<long>(n) * C * 2, 2);
 }
 
+// stats[n][c][which] += sum over the rows of part[n * rows_per_sample + r][which][32 channels]   (fp64, pre-zeroed):
+// the per-workgroup partial sums conv3d_k3_lds<.., STATS> leaves behind (csrc/conv3d.hip).  grid (N, kPartBlocks).
+constexpr int kPartBlocks = 8;
+__global__ __launch_bounds__(256) void instnorm_stats_from_parts(const float* __restrict__ part, int rows_per_sample, int C,
+                                                                 double* __restrict__ stats) {
+  __shared__ double sh[4][64];
+  const int n = blockIdx.x, e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const float* p = part + static_cast<long>(n) * rows_per_sample * 64 + e;
+  double acc = 0.0;
+  for (int r = blockIdx.y * 4 + grp; r < rows_per_sample; r += 4 * kPartBlocks) acc += static_cast<double>(p[static_cast<long>(r) * 64]);
+  sh[grp][e] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    const int which = e >> 5, c = e & 31;
+    if (c < C) atomicAdd(stats + (static_cast<long>(n) * C + c) * 2 + which, sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e]);
+  }
+}
+
 // y = relu((x - mean) * rstd * gamma + beta)
 __global__ __launch_bounds__(kINThreads) void instnorm_apply_relu(
     const unsigned short* __restrict__ x, const double* __restrict__ stats, const float* __restrict__ gamma,
@@ -300,6 +318,25 @@ extern "C" int transoar_instnorm_relu_forward(const void* x, const float* gamma,
   return static_cast<int>(hipGetLastError());
 }
 
+extern "C" int transoar_instnorm_relu_forward_parts(const void* x, const float* gamma, const float* beta, void* y,
+                                                    const float* stat_part, int rows_per_sample, double* stats_ws,
+                                                    float* mean_rstd, int N, long V, int C, float eps, int relu,
+                                                    void* hip_stream) {
+  const int rc = check(x, y, N, V, C);
+  if (rc) return rc;
+  if (!gamma || !beta || !stats_ws || !mean_rstd || !stat_part) return TRANSOAR_IN_ERR_NULL;
+  if (C > 32 || rows_per_sample <= 0) return TRANSOAR_IN_ERR_DIM;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int bps = pick_blocks(V, N, C);
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * N * C, st);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(instnorm_stats_from_parts, dim3(N, kPartBlocks), dim3(256), 0, st, stat_part, rows_per_sample, C, stats_ws);
+  hipLaunchKernelGGL(instnorm_apply_relu, dim3(N * bps), dim3(kINThreads), 0, st,
+                     static_cast<const unsigned short*>(x), stats_ws, gamma, beta, static_cast<unsigned short*>(y),
+                     mean_rstd, V, C, eps, bps, relu);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int transoar_instnorm_relu_backward(const void* x, const void* dy, const float* gamma, const float* beta,
                                                const float* mean_rstd, void* dx, double* red_ws, int N, long V,
                                                int C, int relu, void* hip_stream) {
@@ -319,4 +356,4 @@ extern "C" int transoar_instnorm_relu_backward(const void* x, const void* dy, co
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_instnorm_abi_version(void) { return 1; }
+extern "C" int transoar_instnorm_abi_version(void) { return 2; }

@@ -19,10 +19,12 @@ def _load():
     i, p, lg, f = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
     lib.transoar_instnorm_relu_forward.restype = i
     lib.transoar_instnorm_relu_forward.argtypes = [p, p, p, p, p, p, i, lg, i, f, i, p]
+    lib.transoar_instnorm_relu_forward_parts.restype = i
+    lib.transoar_instnorm_relu_forward_parts.argtypes = [p, p, p, p, p, i, p, p, i, lg, i, f, i, p]
     lib.transoar_instnorm_relu_backward.restype = i
     lib.transoar_instnorm_relu_backward.argtypes = [p, p, p, p, p, p, p, i, lg, i, i, p]
     lib.transoar_instnorm_abi_version.restype = i
-    if lib.transoar_instnorm_abi_version() != 1:
+    if lib.transoar_instnorm_abi_version() != 2:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -38,7 +40,7 @@ def supported(x, channels):
 
 class _InstNormReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, part=None):
         x = to_ndhwc(x)
         n, c = x.shape[:2]
         v = x.shape[2] * x.shape[3] * x.shape[4]
@@ -47,9 +49,16 @@ class _InstNormReLU(torch.autograd.Function):
         ws = torch.empty((n, c, 2), dtype=torch.float64, device=x.device)
         mean_rstd = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = lib.transoar_instnorm_relu_forward(x.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(),
-                                                    ws.data_ptr(), mean_rstd.data_ptr(), n, v, c, float(eps),
-                                                    1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+            if part is not None:
+                # the statistics were taken in the epilogue of the convolution that produced x (conv3d.Conv3dK3.forward_with_stats)
+                rc = lib.transoar_instnorm_relu_forward_parts(x.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(),
+                                                              part.data_ptr(), part.shape[0] // n, ws.data_ptr(), mean_rstd.data_ptr(),
+                                                              n, v, c, float(eps), 1 if relu else 0,
+                                                              torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = lib.transoar_instnorm_relu_forward(x.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(),
+                                                        ws.data_ptr(), mean_rstd.data_ptr(), n, v, c, float(eps),
+                                                        1 if relu else 0, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_instnorm_relu_forward failed with code %d" % rc)
         ctx.save_for_backward(x, g32, b32, mean_rstd)
@@ -71,9 +80,10 @@ class _InstNormReLU(torch.autograd.Function):
         if rc != 0:
             raise RuntimeError("transoar_instnorm_relu_backward failed with code %d" % rc)
         sums = red.sum(0)
-        return dx, sums[:, 1].to(ctx.param_dtype), sums[:, 0].to(ctx.param_dtype), None, None
+        return dx, sums[:, 1].to(ctx.param_dtype), sums[:, 0].to(ctx.param_dtype), None, None, None
 
 
-def instance_norm_relu(x, gamma, beta, eps=1e-5, relu=True):
-    """relu(instance_norm(x) * gamma + beta) for (N,C,D,H,W) bf16 on the GPU."""
-    return _InstNormReLU.apply(x, gamma, beta, eps, relu)
+def instance_norm_relu(x, gamma, beta, eps=1e-5, relu=True, part=None):
+    """relu(instance_norm(x) * gamma + beta) for (N,C,D,H,W) bf16 on the GPU.  part: the per-workgroup partial sums of x's
+    statistics when the producing convolution took them in its epilogue (conv3d.Conv3dK3.forward_with_stats)."""
+    return _InstNormReLU.apply(x, gamma, beta, eps, relu, part)
