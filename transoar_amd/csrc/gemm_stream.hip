@@ -44,6 +44,22 @@ __device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned seed) {
   return x;
 }
 
+// one 1-KiB LDS-DMA piece: lane i fills LDS bytes [16 i, 16 i + 16) of lds_piece from byte voff (per lane) + soff (uniform)
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned soff_in, int voff, unsigned char* lds_piece) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_piece)));
+  const unsigned soff = __builtin_amdgcn_readfirstlane(soff_in);
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+      : "memory");
+}
 // MASK: C = mask(y) ? (A B^T) * drop_scale : 0 with mask(y) = y > 0 read from `gate` (M, N) bf16 -- the gradient of
 // dropout(relu(.)) applied to the product that feeds it (the data gradient of the FFN's second layer): gate is the FFN's
 // saved hidden tensor, whose positive entries are exactly the kept, active ones.
@@ -52,7 +68,10 @@ __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
     unsigned short* __restrict__ C, int M, int N, const int* __restrict__ drop_seed, unsigned thr16, float drop_scale,
     const unsigned short* __restrict__ gate = nullptr) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTile + kK384Waves * kOutBytes];
+  // (MASK: + 4 KiB per wave for the gate values of a tile pair, fetched by LDS-DMA with the weight tile: read in the store
+  // loop itself they were a global-load round trip per 8 tokens with nothing to hide it -- 0.44 ms against 0.25 for the
+  // plain product)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTile + kK384Waves * kOutBytes + (MASK ? kK384Waves * 4096 + 1024 : 0)];
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
   FragBase fs = frag_base(lane);
@@ -71,11 +90,24 @@ __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
   unsigned char* outb = lds + 2 * kTile + wave * kOutBytes;
   const int n_tiles = N >> 5;
 
+  constexpr int kGateOff = ((2 * kTile + kK384Waves * kOutBytes + 1023) / 1024) * 1024;
+  unsigned char* gate_lds = lds + kGateOff + wave * 4096;
+  __amdgpu_buffer_rsrc_t grs = brs;
+  int gate_voff = 0;
+  if (MASK) {
+    grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(gate), 0, static_cast<int>(static_cast<long>(M) * N * 2), 0x00020000);
+    gate_voff = static_cast<int>((static_cast<unsigned>(m0w) + static_cast<unsigned>(lane >> 3)) * static_cast<unsigned>(N) * 2u + static_cast<unsigned>(lane & 7) * 16u);
+  }
   dma_tile<kK384Waves>(brs, 0u, lds, wave, lane);
   dma_wait();
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
     const int st = t & 1;
+    if (MASK && (t & 1)) {          // the gate's 32 tokens x 128 bytes of this tile pair: 4 pieces of 8 tokens
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        dma_piece(grs, static_cast<unsigned>(it * 8) * static_cast<unsigned>(N) * 2u + 64u * static_cast<unsigned>(t - 1), gate_voff, gate_lds + it * 1024);
+    }
     if (t + 1 < n_tiles) dma_tile<kK384Waves>(brs, static_cast<unsigned>(t + 1) * kTile, lds + (st ^ 1) * kTile, wave, lane);
     // C^T[n][token] of the tile: two accumulators, weight fragments fetched six K steps ahead
     f32x16 c0, c1;
@@ -137,7 +169,7 @@ __global__ __launch_bounds__(kK384Waves * 64) void gemm_k384_kernel(
         if (m0w + row < M) {
           if (MASK) {
             // bf16 > 0  <=>  sign bit clear and not zero (the gate holds no NaN: it is a ReLU output)
-            const u32x4 y = *reinterpret_cast<const u32x4*>(gate + (m0w + row) * N + 32 * (t - 1) + 8 * piece);
+            const u32x4 y = *reinterpret_cast<const u32x4*>(gate_lds + it * 1024 + lane * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const unsigned lo = (y[e] & 0xffffu) - 1u < 0x7fffu ? 0x0000ffffu : 0u;
@@ -291,21 +323,6 @@ template <int NT> struct WgTile {
   static constexpr int kIssue = 6 + kPerWave;           // DMA instructions per stage and wave
 };
 
-__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned soff_in, int voff, unsigned char* lds_piece) {
-  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void*)lds_piece)));
-  const unsigned soff = __builtin_amdgcn_readfirstlane(soff_in);
-  unsigned keep;
-  asm volatile(
-      "s_nop 4\n\t"
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
-      : "memory");
-}
 __device__ __forceinline__ s16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
   const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
   const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
