@@ -259,24 +259,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   // requested at once and flies during compute(kt).  Two K steps per trip with the odd one peeled AFTER the loop: the
   // first version left the loop from its middle, and the compiler copied all 64 accumulator registers once per trip
   // (32 v_mov_b64 behind the MFMAs they waited for).
-  // Round 4: TWO register sets again, i.e. a tile is requested two K steps before it is written to LDS.  With one set
-  // (round 3, 32 VGPRs fewer) a load had one compute phase -- 16 MFMAs, ~0.2 us -- to arrive: the counters showed 48 % of
-  // the wave cycles waiting at 44 % MFMA utilisation, two waves per SIMD either way (LDS bounds the occupancy).
-  u32x4 ra1[4], rb1[NB];
   if (kt0 < kt1) {
     load_tile(kt0, ra0, rb0);
     store_tile(0, ra0, rb0);
     if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra0, rb0);
-    if (kt0 + 2 < kt1) load_tile(kt0 + 2, ra1, rb1);
     block_barrier();
     int kt = kt0;
     for (; kt + 2 <= kt1; kt += 2) {
-      store_tile(1, ra0, rb0);                                  // tile kt + 1
-      if (kt + 3 < kt1) load_tile(kt + 3, ra0, rb0);
+      if (kt + 1 < kt1) store_tile(1, ra0, rb0);               // always true here; keeps the two halves alike
+      if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
       compute(0);
       block_barrier();
-      if (kt + 2 < kt1) store_tile(0, ra1, rb1);                // tile kt + 2
-      if (kt + 4 < kt1) load_tile(kt + 4, ra1, rb1);
+      if (kt + 2 < kt1) store_tile(0, ra0, rb0);
+      if (kt + 3 < kt1) load_tile(kt + 3, ra0, rb0);
       compute(1);
       block_barrier();
     }
