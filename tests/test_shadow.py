@@ -164,3 +164,31 @@ def test_focused_decoder_add_norm_on_the_fused_kernel():
     for name, a, b in zip(("y32", "y16", "gx", "gr", "gw", "gb"), res[True], res[False]):
         tol = 2e-2 if name in ("gr", "y16") else 2e-4         # rounded to bf16 on both routes: one ulp apart at most
         assert (a - b).abs().max().item() <= tol * b.abs().max().item(), name
+
+
+def test_mirror_generation_guards_a_backward_that_comes_too_late():
+    """The mirrors are rewritten in place behind autograd's back: a Function that saved a mirror stamps the
+    registry's generation in forward and refuses in backward when a refresh has meanwhile seen changed weights."""
+    from transoar_amd import shadow
+    net = torch.nn.Linear(8, 8)
+    reg = shadow.ShadowWeights(net, stacks=[])
+    reg.refresh()
+    g0 = reg.generation
+    reg.refresh()                                   # nothing changed: same generation (an evaluation pass between two steps)
+    assert reg.generation == g0
+
+    class Ctx:
+        pass
+    ctx = Ctx()
+    with shadow.fresh(reg):
+        shadow.stamp(ctx)
+    shadow.check(ctx)                               # backward right after: fine
+    with torch.no_grad():
+        net.weight.add_(1.0)                        # an optimizer step
+    reg.refresh()
+    assert reg.generation == g0 + 1
+    with pytest.raises(RuntimeError, match="mirrors were refreshed"):
+        shadow.check(ctx)
+    free = Ctx()
+    shadow.stamp(free)                              # no registry in force: nothing to guard
+    shadow.check(free)

@@ -67,12 +67,23 @@ class ShadowWeights:
                 rows = sum(p.shape[0] for p in group)
                 self._stacks[tuple(id(p) for p in group)] = self.flat[start: off].view(rows, *group[0].shape[1:])
         self._ptrs = [p.data_ptr() for p in self.params]
+        # Hard constraint of the mirrors: they are rewritten in place by refresh() through an alias that
+        # autograd's version counters do not see, so a backward pass must run BEFORE the refresh that follows a change of
+        # the weights (TrainStep's order: forward, backward, optimizer step, refresh).  `generation` counts the refreshes
+        # that found changed weights; the autograd Functions that save a mirror stamp it in forward and compare in
+        # backward (stamp / check below) -- two graphs kept alive across an optimizer step raise instead of silently
+        # differentiating with the new weights.
+        self.generation, self._versions = 0, None
 
     def valid(self):
         """False once a parameter was re-allocated (model.to(...), load with assign=True): rebuild then."""
         return all(p.data_ptr() == q and p.dtype == torch.float32 for p, q in zip(self.params, self._ptrs))
 
     def refresh(self):
+        versions = tuple(p._version for p in self.params)
+        if versions != self._versions:
+            self.generation += 1
+            self._versions = versions
         with torch.no_grad():
             torch._foreach_copy_(self._writers, self.params)
 
@@ -106,6 +117,20 @@ class fresh:
         return False
 
 
+def stamp(ctx):
+    """forward of a Function that saves a mirror: remember which state of the weights it saw"""
+    ctx._shadow_stamp = None if _current is None else (_current, _current.generation)
+
+
+def check(ctx):
+    """backward of the same Function: the mirrors must still hold the weights of its forward"""
+    st = getattr(ctx, "_shadow_stamp", None)
+    if st is not None and st[0].generation != st[1]:
+        raise RuntimeError("transoar_amd.shadow: the bf16 weight mirrors were refreshed with changed weights between this "
+                           "forward and its backward (two graphs kept alive across an optimizer step / weight load): the "
+                           "backward would use the new weights.  Run backward before the next step's forward.")
+
+
 def bf16(p):
     """The fresh bf16 mirror of parameter p, or None (no training step in progress / p not mirrored)."""
     return None if _current is None else _current.get(p)
@@ -128,12 +153,14 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, wb, bb):
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
+        stamp(ctx)
         ctx.in_dtype, ctx.has_bias = x.dtype, bias is not None
         with torch.autocast("cuda", enabled=False):
             return F.linear(xb, wb, bb)
 
     @staticmethod
     def backward(ctx, gy):
+        check(ctx)
         xb, wb = ctx.saved_tensors
         gx = gw = gb = None
         with torch.autocast("cuda", enabled=False):
@@ -198,12 +225,14 @@ class _SelfAttnProj(torch.autograd.Function):
         xq = x_qk if x_qk.dtype == torch.bfloat16 else x_qk.to(torch.bfloat16)
         xv = x_v if x_v.dtype == torch.bfloat16 else x_v.to(torch.bfloat16)
         ctx.save_for_backward(xq, xv, wb)
+        stamp(ctx)
         ctx.dtypes = (x_qk.dtype, x_v.dtype)
         with torch.autocast("cuda", enabled=False):
             return F.linear(xq, wb[:2 * c], bb[:2 * c]), F.linear(xv, wb[2 * c:], bb[2 * c:])
 
     @staticmethod
     def backward(ctx, g_qk, g_v):
+        check(ctx)
         xq, xv, wb = ctx.saved_tensors
         c = wb.shape[1]
         with torch.autocast("cuda", enabled=False):

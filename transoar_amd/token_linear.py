@@ -102,6 +102,7 @@ class _TokenLinear(torch.autograd.Function):
             if wb is None:
                 wb = torch.cat((weight, weight2)).to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
+        shadow.stamp(ctx)
         ctx.in_dtype, ctx.has_bias, ctx.force_hip = x.dtype, bias is not None, force_hip
         ctx.split = None if weight2 is None else weight.shape[0]
         global LAST_PATH
@@ -116,6 +117,7 @@ class _TokenLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        shadow.check(ctx)
         xb, wb = ctx.saved_tensors
         gy = gy.to(torch.bfloat16)
         gy2 = gy.reshape(-1, gy.shape[-1])
@@ -148,12 +150,14 @@ class _LinearReluDropout(torch.autograd.Function):
         x2 = xb.reshape(-1, xb.shape[-1])
         y = gemm.linear_relu_dropout(x2, wb, bias, seed, keep_prob)
         ctx.save_for_backward(xb, wb, y)
+        shadow.stamp(ctx)
         ctx.in_dtype, ctx.has_bias, ctx.scale = x.dtype, bias is not None, 1.0 / keep_prob
         return y.view(*xb.shape[:-1], wb.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
         from . import tokens
+        shadow.check(ctx)
         xb, wb, y = ctx.saved_tensors
         gy2 = gy.to(torch.bfloat16).reshape(-1, gy.shape[-1]).contiguous()
         gh = torch.empty_like(y)
@@ -207,12 +211,14 @@ class _FusedFFN(torch.autograd.Function):
         hidden = gemm.linear_relu_dropout(x2, w1b, b1, seed, keep_prob)
         out = gemm.linear_nt(hidden, w2b, b2)
         ctx.save_for_backward(xb, w1b, w2b, hidden)
+        shadow.stamp(ctx)
         ctx.in_dtype, ctx.scale = x.dtype, 1.0 / keep_prob
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         return out.view(*xb.shape[:-1], w2b.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
+        shadow.check(ctx)
         xb, w1b, w2b, hidden = ctx.saved_tensors
         gy2 = gy.to(torch.bfloat16).reshape(-1, gy.shape[-1]).contiguous()
         x2 = xb.reshape(-1, xb.shape[-1])
