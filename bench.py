@@ -62,6 +62,9 @@ def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
 
 BWD_KINDS = ("bwd_query", "cell_count", "scan", "cell_fill", "pull", "value_tile", "value_cells", "bwd_generic")
 PMC_FILE = "r04_msda_pmc.json"
+# the backward as the training step runs it (round 4: transoar_msda3d_backward_proj, bf16 grad_proj instead of fp32
+# grad_loc / grad_attn): FETCH_SIZE / WRITE_SIZE passes of `tools/bench_msda.py --proj`
+PMC_BWD_FILE = "r04_msda_pmc_proj.json"
 
 
 def pmc_traffic(kind, dims):
@@ -69,7 +72,7 @@ def pmc_traffic(kind, dims):
     FETCH_SIZE/WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied), valid only
     for the shape it was collected on; None otherwise."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_BWD_FILE if kind == "bwd" else PMC_FILE)))
         sh = pmc["shape"]
         same = all(sh[k] == dims[k] for k in ("N", "S", "M", "C", "L", "Lq", "P")) and \
             sh["value_dtype"] == ("bf16" if dims["e"] == 2 else "f32")
@@ -372,7 +375,7 @@ def main():
             b = msda_algorithmic_bytes("bwd", **dims)
             msda_bwd = {"kernels": chain, "ms_per_call": round(ms_call, 4), "algorithmic_MB": round(b / 1e6, 1),
                         "achieved_GBps": round(b / ms_call / 1e6, 1), "frac": round(b / ms_call / 1e6 / HBM_PEAK_GBPS, 4),
-                        "traffic": pmc_traffic("bwd", dims), "traffic_unit": "MB per call (PMC, profiles/%s)" % PMC_FILE}
+                        "traffic": pmc_traffic("bwd", dims), "traffic_unit": "MB per call (PMC, profiles/%s)" % PMC_BWD_FILE}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--n", type=int, default=2)
     ap.add_argument("--dtypes", default="f32,bf16")
     ap.add_argument("--dists", default="model,uniform")
+    ap.add_argument("--proj", action="store_true",
+                    help="backward through transoar_msda3d_backward_proj (the training path of round 4: the sampling head's "
+                         "backward folded into the query kernel, bf16 grad_proj instead of fp32 grad_loc / grad_attn)")
     args = ap.parse_args()
     levels = _inputs.VISCERAL_LEVELS if args.geometry == "visceral" else _inputs.AMOS_LEVELS
     for dist in args.dists.split(","):
@@ -65,7 +68,8 @@ def main():
             go = torch.randn(N, Lq, M * C, device="cuda").to(vdt)
             fwd_b, bwd_b = algorithmic_bytes(N, S, M, C, L, Lq, P, v.element_size(), lo.element_size())
             f_med, f_min = time_ms(lambda: MSDA.ms_deform_attn_forward(v, shapes, lsi, lo, at, 64), args.iters)
-            b_med, b_min = time_ms(lambda: MSDA.ms_deform_attn_backward(v, shapes, lsi, lo, at, go, 64), args.iters)
+            bwd = MSDA.ms_deform_attn_backward_proj if (args.proj and dt != "f32" and dt != "f64") else MSDA.ms_deform_attn_backward
+            b_med, b_min = time_ms(lambda: bwd(v, shapes, lsi, lo, at, go, 64), args.iters)
             for name, med, mn, nbytes in (("fwd", f_med, f_min, fwd_b), ("bwd(+zero+cast)", b_med, b_min, bwd_b)):
                 print(json.dumps({"op": "msda3d_" + name, "dist": dist, "dtype": dt, "N": N, "S": S,
                                   "ms_median": round(med, 4), "ms_min": round(mn, 4),
