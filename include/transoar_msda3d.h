@@ -82,8 +82,6 @@ enum {
                                                 * cursors, and every level is accumulated by the brick-owner walk (no fp32 row atomics).
                                                 * A test mode ("deterministic-mode backward"): ~4x the default backward's time;
                                                 * the workspace query must be made with the same flags. */
-#define TRANSOAR_MSDA3D_WGB 128u                /* forward: the workgroup-box gather (msda3d_wgb.hpp: one LDS-DMA-staged union box of value
-                                                * rows per 4-wave workgroup) instead of round 3's point-column one (a private box per wave) */
 #define TRANSOAR_MSDA3D_PULL_HEAD_MAJOR 2u /* schedule experiment: grad_value bricks walked head by head */
 
 /*

@@ -20,7 +20,7 @@ python tools/pmc_summary.py "$OUT" > "$OUT/summary.json"
 python - "$OUT/summary.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))["kernels"]
-for k in ("fwd_wgb", "fwd_pcm", "fwd_mma"):
+for k in ("fwd_pcm", "fwd_mma"):
     if k in d:
         w = d[k].get("SQ_WAVES", 1)
         print(k, {c: round(v / w, 1) for c, v in d[k].items() if c.startswith("SQ_")}, {c: v for c, v in d[k].items() if not c.startswith("SQ_")})

@@ -5,7 +5,7 @@ FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.
 import collections, csv, glob, json, os, re, sys
 
 root = sys.argv[1]
-SHORT = [("msda3d_fwd_wgb", "fwd_wgb"), ("msda3d_fwd_pcm", "fwd_pcm"), ("msda3d_fwd_mma", "fwd_mma"), ("msda3d_bwd_query_mma", "bwd_query_mma"), ("msda3d_fwd_brick", "fwd_brick"), ("msda3d_bwd_query_brick", "bwd_query_brick"),
+SHORT = [("msda3d_fwd_pcm", "fwd_pcm"), ("msda3d_fwd_mma", "fwd_mma"), ("msda3d_bwd_query_mma", "bwd_query_mma"), ("msda3d_fwd_brick", "fwd_brick"), ("msda3d_bwd_query_brick", "bwd_query_brick"),
          ("msda3d_cell_fill_w8", "cell_fill_w8"), ("msda3d_bwd_value_tile", "bwd_value_tile"),
          ("msda3d_bwd_value_cells", "bwd_value_cells"), ("msda3d_coarse_rows_store", "coarse_rows_store"),
          ("msda3d_scan_tiles", "scan_tiles"), ("msda3d_fwd_vec", "fwd_vec"), ("msda3d_bwd_query_vec", "bwd_query_vec"),

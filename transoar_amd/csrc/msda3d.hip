@@ -16,7 +16,6 @@
 #include "msda3d_brick.hpp"
 #include "msda3d_mma.hpp"
 #include "msda3d_pcm.hpp"
-#include "msda3d_wgb.hpp"
 #include "msda3d_tile.hpp"
 #include "msda3d_cells_mma.hpp"
 #include "msda3d_gather.hpp"
@@ -290,13 +289,6 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
         const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
         const PcmConst* cst = device_const(make_pcm_const(order), st);
         if (cst == nullptr) return TRANSOAR_ERR_CONST;
-        if (flags & TRANSOAR_MSDA3D_WGB) {      // workgroup-box form: 4 waves = a 4x2x4 block of queries of one head
-          const long n_wg = n_wave / 4;
-          hipLaunchKernelGGL((msda3d_fwd_wgb<VT, false>), dim3(static_cast<unsigned>(((n_wg + 7) / 8) * 8)), dim3(64 * kWgbWaves), 0, st,
-                             v, lo, at, nullptr, nullptr, 0u, o, d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
-                             static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_wg), cst);
-          return static_cast<int>(hipGetLastError());
-        }
         hipLaunchKernelGGL((msda3d_fwd_pcm<VT, false>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                            v, lo, at, nullptr, nullptr, 0u, o, d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
                            static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_wave), cst);
@@ -356,16 +348,6 @@ static int launch_fwd_fused(const void* value, const void* proj, const float* re
   if (cst == nullptr) return TRANSOAR_ERR_CONST;
   const unsigned ref_bstride = ref_rows == d.Lq ? 0u : static_cast<unsigned>(d.Lq) * d.L * 12u;
   const long proj_bytes = static_cast<long>(d.N) * d.S * 4 * d.M * d.L * d.P * 2;
-  // TRANSOAR_MSDA3D_FUSED_WGB=1 (read per call: the entry has no flags argument): the workgroup-box kernel
-  const char* family = getenv("TRANSOAR_MSDA3D_FUSED_WGB");
-  if (family != nullptr && family[0] == '1') {
-    const long n_wg = n_wave / 4;
-    hipLaunchKernelGGL((msda3d_fwd_wgb<VT, true>), dim3(static_cast<unsigned>(((n_wg + 7) / 8) * 8)), dim3(64 * kWgbWaves), 0, st,
-                       static_cast<const VT*>(value), nullptr, nullptr, static_cast<const unsigned short*>(proj), ref, ref_bstride,
-                       static_cast<VT*>(out), d.S, d.M, d.L, vbytes, static_cast<unsigned>(proj_bytes),
-                       static_cast<unsigned>(ref_rows * d.L * 12), static_cast<unsigned>(n_wg), cst);
-    return static_cast<int>(hipGetLastError());
-  }
   hipLaunchKernelGGL((msda3d_fwd_pcm<VT, true>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                      static_cast<const VT*>(value), nullptr, nullptr, static_cast<const unsigned short*>(proj), ref, ref_bstride,
                      static_cast<VT*>(out), d.S, d.M, d.L, vbytes, static_cast<unsigned>(proj_bytes),
