@@ -35,3 +35,14 @@ def test_explicit_on_is_respected_and_flagged():
 
 def test_opt_in_before_hip_starts():
     assert _run(None, PROBE_OPT_IN) == "0 True"
+
+
+PROBE_LATE_WRITE = ("import os, transoar_amd; os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '0'; "
+                    "print(os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), transoar_amd.graph_replay_safe())")
+
+
+def test_writing_the_variable_after_import_does_not_count():
+    """The runtime reads the switch once; a string written behind the package's back says nothing about what HIP saw
+    (round-4 advisor: the guard must record the opt-in, not re-read the environment)."""
+    assert _run(None, PROBE_LATE_WRITE) == "0 False"
+    assert _run("1", PROBE_LATE_WRITE) == "0 False"

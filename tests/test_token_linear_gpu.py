@@ -91,3 +91,32 @@ def test_fpn_pointwise_convs_as_token_gemms():
         assert rel(g1[k], g0[k]) <= 2.0 ** -5, k
     for k in x0:
         assert rel(x1[k], x0[k]) <= 2.0 ** -5, k
+
+
+def test_ffn_with_hidden_width_384_takes_the_unfused_path():
+    """A refinement block with dim_feedforward == d_model == 384: gemm.stream_kind keeps 384 x 384 products on the tiled
+    kernel, so the fused-FFN predicates must say no (round-4 advisor: they said yes on `hidden % 64 == 0` and the fused
+    nodes then raised in forward and backward) and the layer's token_linear + relu_dropout branch must run."""
+    from transoar_amd import gemm, tokens
+    from transoar_amd.token_linear import fused_ffn_usable, linear_relu_dropout_usable, token_linear
+    torch.manual_seed(0)
+    lin1, lin2 = torch.nn.Linear(384, 384).cuda(), torch.nn.Linear(384, 384).cuda()
+    wide = torch.nn.Linear(384, 1024).cuda()
+    x = torch.randn(1, 20480, 384, device="cuda").to(torch.bfloat16).requires_grad_()
+    drop = torch.nn.Dropout(0.0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert linear_relu_dropout_usable(x, wide.weight) == bool(gemm.STREAM)          # the flagship width still fuses
+        if not gemm.STREAM_SQUARE:
+            assert not linear_relu_dropout_usable(x, lin1.weight)
+            assert not fused_ffn_usable(x, lin1.weight, lin2.weight)
+        # every answer of the predicate is one gemm.stream_kind agrees with
+        for lin in (lin1, wide):
+            if linear_relu_dropout_usable(x, lin.weight):
+                assert gemm.stream_kind(x[0], lin.weight.to(torch.bfloat16)) == "k384"
+        hidden = token_linear(x, lin1.weight, lin1.bias)
+        hidden = tokens.relu_dropout(hidden, drop)
+        y = token_linear(hidden, lin2.weight, lin2.bias)
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x.float(), lin1.weight, lin1.bias)), lin2.weight, lin2.bias)
+    assert (y.float() - ref).abs().max() <= 2.0 ** -5 * ref.abs().max()
+    y.float().sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all() and lin1.weight.grad is not None

@@ -13,21 +13,34 @@ import os as _os
 # it only records what the process was started with, and TrainStep.capture refuses when that is not the safe setting.
 
 
+#: DEBUG_CLR_GRAPH_PACKET_CAPTURE as this process had it when the package was imported -- what HIP sees if it starts later
+_ENV_AT_IMPORT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+_opted_in_before_hip = False
+
+
 def graph_replay_safe():
     """True when HIP graphs are replayed without pre-recorded packets in this process (the setting captured training
-    steps need)."""
-    return _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    steps need): the variable was "0" when the package was imported, or use_safe_graph_replay() set it while HIP was
+    still down.  Writing os.environ later does NOT count -- the runtime has read the switch by then, and a capture
+    that trusted the string would replay wrong gradients silently."""
+    return _ENV_AT_IMPORT == "0" or _opted_in_before_hip
 
 
 def use_safe_graph_replay():
     """Export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 for this process.  Must run before the first HIP call (before any tensor
-    reaches the GPU); raises if HIP is already up with another setting."""
+    reaches the GPU, and before any other library in the process has touched HIP -- only torch's state can be checked
+    here); raises if HIP is already up with another setting."""
+    global _opted_in_before_hip
     import sys
+    if graph_replay_safe():
+        _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+        return
     torch = sys.modules.get("torch")
-    if torch is not None and torch.cuda.is_initialized() and not graph_replay_safe():
+    if torch is not None and torch.cuda.is_initialized():
         raise RuntimeError("HIP is already initialised with graph packet capture on; export "
                            "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process")
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    _opted_in_before_hip = True
 
 
 #: what the process had when this package was imported (kept for callers of the round-2 name)

@@ -559,7 +559,8 @@ extern "C" int transoar_gemm_k384_drop(const void* A, const void* B, const float
 extern "C" int transoar_gemm_k384_gate(const void* A, const void* B, const void* gate, void* C, int M, int N, float scale, void* hip_stream) {
   if (!A || !B || !C || !gate) return TRANSOAR_GEMM_ERR_NULL;
   if (M <= 0 || N <= 0 || (N & 63)) return TRANSOAR_GEMM_ERR_DIM;
-  if (static_cast<long>(N) * kRowBytes >= 0x7ffffff0L || static_cast<long>(M) * N * 2 >= (1L << 40)) return TRANSOAR_GEMM_ERR_DIM;
+  // the gate is read through a buffer descriptor of M * N * 2 bytes and 32-bit byte offsets (a 32-row tile may start past M)
+  if (static_cast<long>(N) * kRowBytes >= 0x7ffffff0L || (static_cast<long>(M) + 32) * N * 2 >= 0xffffffffL) return TRANSOAR_GEMM_ERR_DIM;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(gate)) & 15u)
     return TRANSOAR_GEMM_ERR_ALIGN;
   hipLaunchKernelGGL((gemm_k384_kernel<false, false, true>), dim3(static_cast<unsigned>((M + 32 * kK384Waves - 1) / (32 * kK384Waves))),

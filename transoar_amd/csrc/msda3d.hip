@@ -479,7 +479,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
                            static_cast<int>(cells_per_slab), d.S, d.M, d.L, n_wave, order_d);
       }
       scan();
-      det = det_req && cells_per_slab * d.N * d.M + 2 <= w.n_scan && w.n_points < (1L << 32);
+      det = det_req && cells_per_slab * d.N * d.M + 2 <= w.n_scan && w.n_points < (1L << 31);      // the sort takes the count as an int
       if (det_req && !det) return TRANSOAR_ERR_MODE;
       if (!det) {
         ProfScope prof(TRANSOAR_PROF_BWD_QUERY, st);

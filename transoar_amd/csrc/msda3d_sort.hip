@@ -10,6 +10,7 @@ namespace transoar {
 // holds the result in *sorted.  temp == nullptr: only reports the scratch size in *temp_bytes.
 int sort_keys64(unsigned long long* keys, unsigned long long* alt, long n, int end_bit, void* temp, size_t* temp_bytes,
                 unsigned long long** sorted, hipStream_t st) {
+  if (n < 0 || n >= (1L << 31)) return static_cast<int>(hipErrorInvalidValue);      // hipCUB takes the count as an int
   hipcub::DoubleBuffer<unsigned long long> buf(keys, alt);
   const hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, *temp_bytes, buf, static_cast<int>(n), 0, end_bit, st);
   if (sorted != nullptr) *sorted = buf.Current();

@@ -128,13 +128,19 @@ class GradientAllReducer:
             torch._foreach_copy_([v for _, v in live], [p.grad for p, _ in live])
             for p, v in live:
                 p.grad = v
-        if self._first_step:                      # parameters without a gradient: zero slices (they are dropped after this step)
-            for p, v in zip(b.params, b.views):
-                if p.grad is None:
-                    v.zero_()
+        # a parameter of the bucket without a gradient this step contributes ZERO to the exchange, not last step's slice
+        # (first step: every parameter that has not fired; later: a live parameter whose branch was skipped on this rank)
+        for p, v in zip(b.params, b.views):
+            if p.grad is None and p not in self._dead:
+                v.zero_()
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
+        if p in self._dead:
+            # the bucket no longer counts it (b.expected): packing would start before the live gradients are in, and the
+            # other ranks would not expect the slice
+            raise RuntimeError("GradientAllReducer: a parameter that had no gradient in the first step received one later; "
+                               "rebuild the reducer when the set of trained parameters changes")
         if self._first_step:
             self._fired.add(p)
         b.pending -= 1

@@ -71,6 +71,14 @@ def stream_kind(x, w, out_dtype=None, relu=False):
     return None
 
 
+def k384_takes(m, n):
+    """Would `stream_kind` give the K = 384 streaming kernel an (m, 384) x (n, 384) product of dense, aligned bf16
+    operands?  The shape part of its answer, for callers that decide before the bf16 operands exist; `gated` products
+    (linear_gate) also read an (m, n) bf16 gate through a 32-bit byte offset."""
+    return bool(STREAM and m >= 16384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE)
+                and (m + 32) * n * 2 < 0xffffffff)
+
+
 def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
     """x (M, K), w (N, K) -> (M, N) = x @ w.T (+ bias) (ReLU); bias fp32 (N,)."""
     if not usable(x, w):
@@ -175,6 +183,8 @@ def linear_gate(x, w, gate, scale):
     if stream_kind(x, w) != "k384" or gate.shape != (x.shape[0], w.shape[0]) or gate.dtype != torch.bfloat16 or not gate.is_contiguous():
         raise RuntimeError("linear_gate: needs the K = 384 streaming kernel (dense bf16 operands, >= 16384 rows) and a dense bf16 gate")
     m, n = x.shape[0], w.shape[0]
+    if (m + 32) * n * 2 >= 0xffffffff:
+        raise RuntimeError("linear_gate: the gate is addressed with 32-bit byte offsets; chunk over the rows")
     out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib.transoar_gemm_k384_gate(x.data_ptr(), w.data_ptr(), gate.data_ptr(), out.data_ptr(), m, n, float(scale),

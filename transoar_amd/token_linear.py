@@ -182,7 +182,10 @@ def linear_relu_dropout_usable(x, weight):
             and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
         return False
     x2 = x.reshape(-1, x.shape[-1])
-    return USE_HIP_GEMM is not False and x2.shape[1] == 384 and x2.shape[0] >= 16384 and weight.shape[0] % 64 == 0 and gemm.STREAM
+    # exactly the products gemm.stream_kind hands to the K = 384 kernel (a hidden width of 384 is not one of them unless
+    # TRANSOAR_GEMM_STREAM_SQUARE is set), on operands the C entry points accept (16-byte aligned)
+    return (USE_HIP_GEMM is not False and x2.shape[1] == 384 and weight.shape[1] == 384 and x2.data_ptr() % 16 == 0
+            and gemm.k384_takes(x2.shape[0], weight.shape[0]))
 
 
 def linear_relu_dropout(x, weight, bias, dropout):
