@@ -17,3 +17,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- observed errors: tests call tests._observe.observe(key, value, bound) next to the assertion that bounds `value`; the
+# session writes the maxima to gpurun_out/observed_errors.json, from where they are copied to profiles/ and the bounds
+# are set at ~2x (round-4 VERDICT item 9: "bounds nobody has looked under")
+def pytest_sessionfinish(session, exitstatus):
+    from tests import _observe
+    _observe.dump(os.path.join(ROOT, "gpurun_out", "observed_errors.json"))

@@ -18,6 +18,7 @@ no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
     python tests/golden/make_golden.py --models   # additionally g6 (backbone), g7 (whole model)
     python tests/golden/make_golden.py --swin     # only g8 (Swin encoder backbone)
     python tests/golden/make_golden.py --swin-stage   # only g9 (one full-width Swin stage: head dimension 32)
+    python tests/golden/make_golden.py --flagship     # only g10 (full-width flagship eval forward, one volume; minutes)
 
 g6/g7 import the reference's full model, which needs two container-only shims
 (a stub ``timm.models.layers`` and ``Tensor.cuda = identity``).
@@ -298,6 +299,38 @@ def g7_whole_model():
     np.savez_compressed(os.path.join(HERE, "g7_whole_model.npz"), **store)
 
 
+def g10_flagship_forward():
+    """The FULL-WIDTH flagship (config/attn_fpn_foc_dec_visceral.yaml with the refinement on = BASELINE.json configs #2/#3:
+    384 channels, 6 heads, 4 levels, S = 117 000), one 160x160x256 analytic volume, eval forward in fp32 on the
+    reference's use_cuda=False path: logits and boxes of the three decoder layers.  Weights: fill_deterministic with a
+    gain that keeps activations O(1) through the 12-conv encoder.  Minutes of CPU time and ~25 GB here; the fixture is
+    14 KB of outputs (round-4 VERDICT item 9: config #2 pinned at the width the bench times)."""
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import analytic_volume, fill_deterministic
+    from transoar_amd.config import synthetic_bbox_properties, visceral_config
+    from transoar.models.transoarnet import TransoarNet
+    cfg = visceral_config(refine=True, use_cuda=False)
+    cfg["bbox_properties"] = synthetic_bbox_properties(20, seed=0)
+    torch.manual_seed(0)
+    net = TransoarNet(cfg).eval()
+    fill_deterministic(net, gain=G10_GAIN)
+    x = analytic_volume((160, 160, 256), batch=1)
+    with torch.no_grad():
+        out = net(x)
+    store = {"pred_logits": out["pred_logits"].numpy(), "pred_boxes": out["pred_boxes"].numpy(),
+             "anchors": net._anchors.numpy(), "gain": np.float64(G10_GAIN)}
+    for i, aux in enumerate(out["aux_outputs"]):
+        store["aux%d_logits" % i] = aux["pred_logits"].numpy()
+        store["aux%d_boxes" % i] = aux["pred_boxes"].numpy()
+    np.savez_compressed(os.path.join(HERE, "g10_flagship_forward.npz"), **store)
+    print("g10: logits range", float(out["pred_logits"].min()), float(out["pred_logits"].max()),
+          "boxes std", float(out["pred_boxes"].std()))
+
+
+G10_GAIN = 1.0
+
+
 def g8_swin_backbone():
     """AttnFPN with use_encoder_attn=True (Swin stages 2-5; BASELINE config #4 at reduced width) on a 32x32x64
     volume: window / shifted-window blocks with padding (16x16x32, 8x8x16 grids), a mixed case (4x4x8: one
@@ -364,6 +397,10 @@ if __name__ == "__main__" and "--swin-stage" in sys.argv:
 
 if __name__ == "__main__" and "--swin" in sys.argv:
     g8_swin_backbone()
+    sys.exit(0)
+
+if __name__ == "__main__" and "--flagship" in sys.argv:
+    g10_flagship_forward()
     sys.exit(0)
 
 if __name__ == "__main__" and "--models" in sys.argv:

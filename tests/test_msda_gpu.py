@@ -44,6 +44,12 @@ TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -7, tor
 # element-wise: fp32 sums of <= 128 products (1e-4 again); 16-bit storage: the output rounding 2^-8 / 2^-11 plus the
 # rounding of a sum whose terms may cancel (a 1 %-of-max entry can be the difference of 10x larger terms)
 ELEM_TOL = {torch.float64: 1e-9, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -4, torch.float16: 2.0 ** -7}
+# the full-size bf16 kernels against the C oracle on the same bf16 inputs, element-wise (observed maxima in
+# profiles/r05_observed_errors.json; bounds ~2x observed)
+FULL_ELEM_OUT, FULL_ELEM_GRAD = 2.0 ** -4, 2e-3
+
+
+from tests._observe import observe  # noqa: E402
 
 
 def elem_relerr(a, b, floor=0.01):
@@ -88,6 +94,13 @@ def test_golden_vectors(MSDA, golden_dir, fixture, generic):
             assert relerr(gv, c["grad_value"]) <= tol, (prefix, "grad_value")
             assert relerr(ga, c["grad_attn"]) <= tol, (prefix, "grad_attn")
             etol = ELEM_TOL[dt]
+            tag = "msda.golden.%s." % str(dt).split(".")[-1]
+            observe(tag + "out.max_norm", relerr(out, c["out"]), tol)
+            observe(tag + "grad_value.max_norm", relerr(gv, c["grad_value"]), tol)
+            observe(tag + "grad_attn.max_norm", relerr(ga, c["grad_attn"]), tol)
+            observe(tag + "out.elem", elem_relerr(out, c["out"]), etol)
+            observe(tag + "grad_value.elem", elem_relerr(gv, c["grad_value"]), etol)
+            observe(tag + "grad_attn.elem", elem_relerr(ga, c["grad_attn"]), etol)
             assert elem_relerr(out, c["out"]) <= etol, (prefix, "out, element-wise", elem_relerr(out, c["out"]))
             assert elem_relerr(gv, c["grad_value"]) <= etol, (prefix, "grad_value, element-wise", elem_relerr(gv, c["grad_value"]))
             assert elem_relerr(ga, c["grad_attn"]) <= etol, (prefix, "grad_attn, element-wise", elem_relerr(ga, c["grad_attn"]))
@@ -446,15 +459,22 @@ def test_full_size_16bit_kernels_vs_c_oracle(MSDA, geom, dist, vdt):
     f = lambda t: t.float().cpu().numpy()
     pc = pick.cuda()
     ref = c_oracle.forward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]), f(attn[:, pc]))
+    tag = "msda.full_size.%s.%s." % (geom, dist)
+    observe(tag + "out.max_norm", relerr(out[:, pc], torch.from_numpy(ref)), TOL[vdt])
+    observe(tag + "out.elem", elem_relerr(out[:, pc], torch.from_numpy(ref)), FULL_ELEM_OUT)
     assert relerr(out[:, pc], torch.from_numpy(ref)) <= TOL[vdt]
     # element-wise on the entries above 1 % of the tensor maximum (the timed bf16 kernels at the timed size)
-    assert elem_relerr(out[:, pc], torch.from_numpy(ref)) <= ELEM_TOL[vdt], elem_relerr(out[:, pc], torch.from_numpy(ref))
+    assert elem_relerr(out[:, pc], torch.from_numpy(ref)) <= FULL_ELEM_OUT, elem_relerr(out[:, pc], torch.from_numpy(ref))
     _, rgl, rga = c_oracle.backward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]),
                                     f(attn[:, pc]), f(go[:, pc]))
+    observe(tag + "grad_loc.max_norm", relerr(gl[:, pc], torch.from_numpy(rgl)), 1e-4)
+    observe(tag + "grad_attn.max_norm", relerr(ga[:, pc], torch.from_numpy(rga)), 1e-4)
+    observe(tag + "grad_loc.elem", elem_relerr(gl[:, pc], torch.from_numpy(rgl)), FULL_ELEM_GRAD)
+    observe(tag + "grad_attn.elem", elem_relerr(ga[:, pc], torch.from_numpy(rga)), FULL_ELEM_GRAD)
     assert relerr(gl[:, pc], torch.from_numpy(rgl)) <= 1e-4
     assert relerr(ga[:, pc], torch.from_numpy(rga)) <= 1e-4
-    assert elem_relerr(gl[:, pc], torch.from_numpy(rgl)) <= 2e-3, elem_relerr(gl[:, pc], torch.from_numpy(rgl))
-    assert elem_relerr(ga[:, pc], torch.from_numpy(rga)) <= 2e-3, elem_relerr(ga[:, pc], torch.from_numpy(rga))
+    assert elem_relerr(gl[:, pc], torch.from_numpy(rgl)) <= FULL_ELEM_GRAD, elem_relerr(gl[:, pc], torch.from_numpy(rgl))
+    assert elem_relerr(ga[:, pc], torch.from_numpy(rga)) <= FULL_ELEM_GRAD, elem_relerr(ga[:, pc], torch.from_numpy(rga))
     # grad_value: adjoint of the (linear in value) forward
     u = torch.randn(v.shape, device="cuda", generator=g).to(vdt)
     fu = MSDA.ms_deform_attn_forward(u, shapes, lsi, loc, attn, 64)
@@ -629,6 +649,7 @@ def test_deterministic_backward_is_bit_stable_and_agrees_with_default(MSDA, geom
             assert torch.equal(a, b)
     assert not torch.isnan(runs[0][0].float()).any()
     assert torch.equal(runs[0][1], ref[1]) and torch.equal(runs[0][2], ref[2])
+    observe("msda.deterministic.grad_value.elem", elem_relerr(runs[0][0], ref[0]), ELEM_TOL[torch.bfloat16])
     assert relerr(runs[0][0], ref[0]) <= TOL[torch.bfloat16]
     assert elem_relerr(runs[0][0], ref[0]) <= ELEM_TOL[torch.bfloat16]
 
