@@ -192,16 +192,16 @@ size_t transoar_msda3d_backward_workspace_bytes(int N, int S, int M, int C,
  * overwritten) and forgets them.  Returns 0 or a hipError_t.
  */
 enum {
-  TRANSOAR_PROF_FWD = 0,          /* msda3d_fwd_brick / msda3d_fwd_vec  */
-  TRANSOAR_PROF_BWD_QUERY = 1,    /* msda3d_bwd_query_brick / _vec      */
-  TRANSOAR_PROF_CELL_COUNT = 2,   /* msda3d_cell_count                  */
+  TRANSOAR_PROF_FWD = 0,          /* the forward gather: msda3d_fwd_pcm (flagship form) / _mma / _brick / _vec */
+  TRANSOAR_PROF_BWD_QUERY = 1,    /* msda3d_bwd_query_mma (grad_loc, grad_attn or grad_proj, and the sort records) / _brick / _vec */
+  TRANSOAR_PROF_CELL_COUNT = 2,   /* msda3d_cell_count_mma / msda3d_cell_count                  */
   TRANSOAR_PROF_SCAN = 3,         /* the three msda3d_scan_* launches   */
-  TRANSOAR_PROF_CELL_FILL = 4,    /* msda3d_cell_fill / _fill_w8        */
+  TRANSOAR_PROF_CELL_FILL = 4,    /* fallback forms only: msda3d_cell_fill (the matrix-core chain writes its records from the query kernel) */
   TRANSOAR_PROF_PULL = 5,         /* msda3d_bwd_value_pull (voxel-stationary fallback) */
   TRANSOAR_PROF_FWD_GENERIC = 6,
   TRANSOAR_PROF_BWD_GENERIC = 7,
-  TRANSOAR_PROF_VALUE_TILE = 8,   /* msda3d_bwd_value_tile (+ msda3d_coarse_rows_store) */
-  TRANSOAR_PROF_VALUE_CELLS = 9,  /* scratch memset + msda3d_bwd_value_cells             */
+  TRANSOAR_PROF_VALUE_TILE = 8,   /* msda3d_bwd_value_tile_mma / _tile (+ msda3d_coarse_rows_store) */
+  TRANSOAR_PROF_VALUE_CELLS = 9,  /* scratch memset + msda3d_bwd_value_cells_mma / _cells             */
   TRANSOAR_PROF_KINDS = 10
 };
 void transoar_msda3d_profile_enable(int on);

@@ -177,8 +177,9 @@ def test_g7_whole_model_and_criterion(golden_dir, debug_core, device, tag, refin
         tol = 1e-3 if device == "cpu" else 5e-2
         if device != "cpu" and name.startswith("_backbone._encoder._stages.0."):
             # the very first convs sit behind 12 InstanceNorms: their fp32 gradient checksum moves by
-            # >10 % between two CPU evaluations already (tests/test_data_parallel.py); sanity bound only
-            tol = 0.5
+            # >10 % between two CPU evaluations already (tests/test_data_parallel.py); observed on the GPU 0.124 (refine) /
+            # 0.038 (plain), everything else 0.026 against its 0.05 (profiles/r05_observed_errors.json): 2x observed
+            tol = 0.25
         if device != "cpu":
             key = "g7.%s.grad_checksum.%s" % (tag, "encoder_stage0" if name.startswith("_backbone._encoder._stages.0.") else "rest")
             observe(key, abs(g.double().sum().item() - s) / max(a, 1e-6), tol)
@@ -273,13 +274,14 @@ def test_bf16_training_path_reaches_every_parameter(debug_core, refine):
     observe("model.bf16_vs_fp32.grad_rel_l2.median", rel[len(rel) // 2][0], 6e-2)
     observe("model.bf16_vs_fp32.grad_rel_l2.p90", rel[int(0.9 * len(rel))][0], 0.4)
     observe("model.bf16_vs_fp32.grad_rel_l2.max_outside_first_norm", max(r for r, n in rel if "_stages.0._block.1." not in n), 0.6)
-    observe("model.bf16_vs_fp32.grad_rel_l2.first_norm", max([r for r, n in rel if "_stages.0._block.1." in n] or [0.0]), 2.5)
+    observe("model.bf16_vs_fp32.grad_rel_l2.first_norm", max([r for r, n in rel if "_stages.0._block.1." in n] or [0.0]), 2.2)
     assert rel[len(rel) // 2][0] <= 6e-2, rel[len(rel) // 2]
     assert rel[int(0.9 * len(rel))][0] <= 0.4, rel[int(0.9 * len(rel)):][:5]
     # per-tensor bound (round-2 VERDICT weak #2): every tensor <= 0.6 (observed <= 0.39) except the two named ones -- the
     # affine parameters of the FIRST InstanceNorm, behind all 12 norm layers of the encoder, where two fp32 runs already
     # differ by > 10 % (tests/test_data_parallel.py): observed 0.58 / 1.14
-    ill = {"_backbone._encoder._stages.0._block.1.weight": 2.5, "_backbone._encoder._stages.0._block.1.bias": 2.5}
+    # (round 5, profiles/r05_observed_errors.json: median 0.032, p90 0.265, max elsewhere 0.387, the two named ones 1.09)
+    ill = {"_backbone._encoder._stages.0._block.1.weight": 2.2, "_backbone._encoder._stages.0._block.1.bias": 2.2}
     over = [(r, n) for r, n in rel if r > ill.get(n, 0.6)]
     assert not over, over
 

@@ -41,12 +41,15 @@ def relerr(a, b):
 # tests/ and in bench.py's `parity` field).  elem_relerr() below bounds the element-wise relative error as well, on the
 # entries that are not tiny (|b| > 1 % of the tensor maximum) -- round-3 VERDICT weak #1.
 TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
-# element-wise: fp32 sums of <= 128 products (1e-4 again); 16-bit storage: the output rounding 2^-8 / 2^-11 plus the
-# rounding of a sum whose terms may cancel (a 1 %-of-max entry can be the difference of 10x larger terms)
-ELEM_TOL = {torch.float64: 1e-9, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -4, torch.float16: 2.0 ** -7}
-# the full-size bf16 kernels against the C oracle on the same bf16 inputs, element-wise (observed maxima in
-# profiles/r05_observed_errors.json; bounds ~2x observed)
-FULL_ELEM_OUT, FULL_ELEM_GRAD = 2.0 ** -4, 2e-3
+# element-wise: fp32 sums of <= 128 products (1e-4 again; observed 5e-6); 16-bit storage: the output rounding 2^-8 / 2^-11
+# plus the rounding of a sum whose terms may cancel.  Observed maxima of every bound below: profiles/r05_observed_errors.json
+# (written by tests/_observe.py); round 5 set the 16-bit bounds at 2x what was observed (they were 2^-4 / 2e-3 / 1e-4:
+# bounds nobody had looked under, round-4 VERDICT weak #1): bf16 grad_value element-wise 2^-7 observed -> 2^-6
+ELEM_TOL = {torch.float64: 1e-9, torch.float32: 1e-4, torch.bfloat16: 2.0 ** -6, torch.float16: 2.0 ** -9}
+# the full-size bf16 kernels against the C oracle on the same bf16 inputs: out element-wise 3.99e-3 observed (the bf16
+# output rounding, 2^-8) -> 2^-7; grad_loc / grad_attn (fp32 outputs) element-wise 1e-5 observed -> 5e-5, tensor-max
+# normalised 4.1e-7 observed -> 2e-6
+FULL_ELEM_OUT, FULL_ELEM_GRAD, FULL_MAXNORM_GRAD = 2.0 ** -7, 5e-5, 2e-6
 
 
 from tests._observe import observe  # noqa: E402
@@ -467,12 +470,12 @@ def test_full_size_16bit_kernels_vs_c_oracle(MSDA, geom, dist, vdt):
     assert elem_relerr(out[:, pc], torch.from_numpy(ref)) <= FULL_ELEM_OUT, elem_relerr(out[:, pc], torch.from_numpy(ref))
     _, rgl, rga = c_oracle.backward(f(v), f(shapes).astype(np.int64), f(lsi).astype(np.int64), f(loc[:, pc]),
                                     f(attn[:, pc]), f(go[:, pc]))
-    observe(tag + "grad_loc.max_norm", relerr(gl[:, pc], torch.from_numpy(rgl)), 1e-4)
-    observe(tag + "grad_attn.max_norm", relerr(ga[:, pc], torch.from_numpy(rga)), 1e-4)
+    observe(tag + "grad_loc.max_norm", relerr(gl[:, pc], torch.from_numpy(rgl)), FULL_MAXNORM_GRAD)
+    observe(tag + "grad_attn.max_norm", relerr(ga[:, pc], torch.from_numpy(rga)), FULL_MAXNORM_GRAD)
     observe(tag + "grad_loc.elem", elem_relerr(gl[:, pc], torch.from_numpy(rgl)), FULL_ELEM_GRAD)
     observe(tag + "grad_attn.elem", elem_relerr(ga[:, pc], torch.from_numpy(rga)), FULL_ELEM_GRAD)
-    assert relerr(gl[:, pc], torch.from_numpy(rgl)) <= 1e-4
-    assert relerr(ga[:, pc], torch.from_numpy(rga)) <= 1e-4
+    assert relerr(gl[:, pc], torch.from_numpy(rgl)) <= FULL_MAXNORM_GRAD
+    assert relerr(ga[:, pc], torch.from_numpy(rga)) <= FULL_MAXNORM_GRAD
     assert elem_relerr(gl[:, pc], torch.from_numpy(rgl)) <= FULL_ELEM_GRAD, elem_relerr(gl[:, pc], torch.from_numpy(rgl))
     assert elem_relerr(ga[:, pc], torch.from_numpy(rga)) <= FULL_ELEM_GRAD, elem_relerr(ga[:, pc], torch.from_numpy(rga))
     # grad_value: adjoint of the (linear in value) forward
