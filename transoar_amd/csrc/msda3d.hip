@@ -289,16 +289,6 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
         const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
         const PcmConst* cst = device_const(make_pcm_const(order), st);
         if (cst == nullptr) return TRANSOAR_ERR_CONST;
-        if constexpr (sizeof(VT) == 2) {
-          const char* pr = getenv("TRANSOAR_PCM_PROBE");
-          if (pr != nullptr && pr[0] >= '1' && pr[0] <= '3') {
-            auto kern = pr[0] == '1' ? msda3d_fwd_pcm<bf16_t, false, 1> : pr[0] == '2' ? msda3d_fwd_pcm<bf16_t, false, 2> : msda3d_fwd_pcm<bf16_t, false, 3>;
-            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
-                               reinterpret_cast<const bf16_t*>(v), lo, at, nullptr, nullptr, 0u, reinterpret_cast<bf16_t*>(o), d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
-                               static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_wave), cst);
-            return static_cast<int>(hipGetLastError());
-          }
-        }
         hipLaunchKernelGGL((msda3d_fwd_pcm<VT, false>), dim3(static_cast<unsigned>(((n_wave + 7) / 8) * 8)), dim3(64), 0, st,
                            v, lo, at, nullptr, nullptr, 0u, o, d.S, d.M, d.L, vbytes, static_cast<unsigned>(n_pts * 12),
                            static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_wave), cst);

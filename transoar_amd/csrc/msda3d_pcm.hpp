@@ -126,7 +126,7 @@ struct PcmConst {
   float dD[4], dH[4], dW[4];          // FUSED: what the autocast chain divides the offsets by: bf16(size)
 };
 
-template <typename VT, bool FUSED, int PROBE = 0>
+template <typename VT, bool FUSED>
 __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
     const VT* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const unsigned short* __restrict__ proj, const float* __restrict__ ref, unsigned ref_bstride,
@@ -357,17 +357,6 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
     }
   }
 
-  if constexpr (PROBE == 1) {          // prologue only: keep every result alive
-    unsigned x = 0;
-#pragma unroll
-    for (int l = 0; l < kPcmLevels; ++l) {
-      x ^= static_cast<unsigned>(pdhw[l]) ^ static_cast<unsigned>(mode[l] + box[l].bd + box[l].TD + box[l].TH * box[l].TW + box[l].bh + box[l].bw);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) x ^= wq[l][c];
-    }
-    if (x == 0x12345u) reinterpret_cast<unsigned*>(out)[lane] = x;
-    return;
-  }
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -457,7 +446,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
         for (int it = 2; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_swz) = pre[it];
       }
       // ---- the lane's four entries for the 64 rows that start here: slot inside the block, or the spare slot
-      if (sub == 0 && PROBE != 3) {
+      if (sub == 0) {
         const int k0 = hb * KB;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -481,7 +470,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
         }
       }
       // ---- 16-row chunks on the matrix cores
-      for (int kc = 0; kc < (PROBE == 2 ? 0 : nch); ++kc) {
+      for (int kc = 0; kc < nch; ++kc) {
         const unsigned* wp = wcol + sub * KB + kc * 16 + 8 * kh;
         const u32x4 p0 = *reinterpret_cast<const u32x4*>(wp);
         const u32x4 p1 = *reinterpret_cast<const u32x4*>(wp + 4);
@@ -506,7 +495,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
         acc1 = Mma<VT>::mfma(wlo, v1, acc1);
       }
       // ---- clear the entries again when their 64 rows are done
-      if ((sub == KW / KB - 1 || hb + 1 == nh) && PROBE != 3) {
+      if (sub == KW / KB - 1 || hb + 1 == nh) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) wcol[wad[c]] = 0u;
       }
