@@ -49,6 +49,24 @@ __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
 }
+// 64 lanes x 16 bytes global -> LDS by DMA (buffer_load_dwordx4 ... lds): lane i lands at LDS byte dst + 16 i (dst wave-uniform).
+// Inline assembly: hipcc neither counts these loads nor waits for them -- dma_wait() before the barrier that publishes a
+// stage does (mfma_stream.hpp explains why the builtin is not used).
+typedef __attribute__((address_space(3))) void conv_lds_void;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned dst) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // LDS-only barrier (see gemm.hip): does not drain the global loads in flight
 __device__ __forceinline__ void block_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -190,30 +208,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
   // instructions per MFMA): the tap of this thread's piece indexes ONE packed table entry and ONE bit of the row's map;
   // an invalid A source gets bit 31 set (past the buffer: zeros), an invalid filter piece the offset kInvalid (2^30,
   // past any filter pack -- checked on the host -- also when row and piece are both invalid: 2^31).
-  u32x4 ra0[4], rb0[NB];
-  auto load_tile = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[NB]) {
-    const int j = kt * 8 + s_piece;                               // this thread's piece of the flattened (tap, channel) axis
+  // Round 5: the operand tiles go global -> LDS by DMA.  Round 3 staged them through registers: 8 ds_write_b128 per thread
+  // and K step, 13 cycles each on the CU's store path (profiles/r05_ubench_instruction_rates.txt) -- 36 % of the kernel's
+  // time at two workgroups per CU, and 32 staging registers.  Lane L of wave w fills bytes [16 L, 16 L + 16) of the 1 KiB
+  // that holds rows w * 8 + (L >> 3) + 32 i, i.e. the PHYSICAL piece s_piece of row s_row + 32 i; the swizzle key
+  // ((row >> 1) & 7) is the same for a thread's rows (32 i >> 1 = 16 i), so the thread fetches ONE logical piece of the
+  // flattened (tap, channel) axis per K step, as before.
+  const int l_piece = s_piece ^ ((s_row >> 1) & 7);
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((conv_lds_void*)&lds[0][0]));
+  constexpr unsigned kStage = kTile + BNT * BK * 2;
+  const unsigned dst_a = __builtin_amdgcn_readfirstlane(lds0 + static_cast<unsigned>(wave) * 1024u);
+  auto dma_tile = [&](int kt, int stage) {
+    const int j = kt * 8 + l_piece;                               // this thread's piece of the flattened (tap, channel) axis
     const int tap = min(static_cast<int>((static_cast<float>(j) + 0.5f) * inv_pt), 31);      // j >= pieces -> tap >= ntaps
     const int c8 = j - __mul24(tap, PT);
     const int2 tt = tap_tab[tap];
     const unsigned src = static_cast<unsigned>(tt.x + c8 * 16), wof = static_cast<unsigned>(tt.y + c8 * 16);
+    const unsigned base = dst_a + static_cast<unsigned>(stage) * kStage;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (a_base[i] + src) | (((a_inv[i] >> tap) & 1u) << 31), 0, 0);
+      dma16(rx, (a_base[i] + src) | (((a_inv[i] >> tap) & 1u) << 31), base + i * 4096u);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_base[i] + wof, 0, 0);
-  };
-  auto store_tile = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[NB]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = s_row + 32 * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int r = s_row + 32 * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][kTile + r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = rb[i];
-    }
+    for (int i = 0; i < NB; ++i) dma16(rw, b_base[i] + wof, base + kTile + i * 4096u);
   };
 
   f32x16 acc[TN][2];          // [n tile][m tile] of the wave's part, D = [n][m]
@@ -255,24 +271,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(
         for (int b = 0; b < 2; ++b) acc[a][b] = mfma(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
     }
   };
-  // One register set: tile kt + 1 is written to the other LDS stage right after the barrier that freed it, tile kt + 2 is
-  // requested at once and flies during compute(kt).  Two K steps per trip with the odd one peeled AFTER the loop: the
-  // first version left the loop from its middle, and the compiler copied all 64 accumulator registers once per trip
-  // (32 v_mov_b64 behind the MFMAs they waited for).
+  // Stage s is multiplied while the DMA of the next K step fills stage s ^ 1; the barrier at the end of a step says both
+  // "everyone has read stage s" and (behind each wave's own dma_wait) "stage s ^ 1 has landed".
   if (kt0 < kt1) {
-    load_tile(kt0, ra0, rb0);
-    store_tile(0, ra0, rb0);
-    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra0, rb0);
+    dma_tile(kt0, 0);
+    dma_wait();
     block_barrier();
     int kt = kt0;
     for (; kt + 2 <= kt1; kt += 2) {
-      if (kt + 1 < kt1) store_tile(1, ra0, rb0);               // always true here; keeps the two halves alike
-      if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
+      dma_tile(kt + 1, 1);
       compute(0);
+      dma_wait();
       block_barrier();
-      if (kt + 2 < kt1) store_tile(0, ra0, rb0);
-      if (kt + 3 < kt1) load_tile(kt + 3, ra0, rb0);
+      if (kt + 2 < kt1) dma_tile(kt + 2, 0);
       compute(1);
+      dma_wait();
       block_barrier();
     }
     if (kt < kt1) {                                             // odd count: the last tile sits in stage 0
