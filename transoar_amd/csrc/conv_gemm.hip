@@ -423,9 +423,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   // staging: a K step is WK rows x PR pieces per operand = 8 WK TW pieces of 16 bytes: NS per thread and operand
   constexpr int NS = WK * PR / 256, RS = 256 / PR;                // pieces per thread, rows per pass
   const int s_piece = tid % PR, s_row = tid / PR;                 // rows s_row + RS i
-  const bool co_ok = co0 + s_piece * 8 < g.Cout, ci_ok = ci0 + s_piece * 8 < g.Cin;
-  const unsigned y_col = co_ok ? static_cast<unsigned>(co0 + s_piece * 8) * 2u : 0x80000000u;
-  const unsigned x_col = ci_ok ? static_cast<unsigned>(ci0 + s_piece * 8) * 2u : 0x80000000u;
+  // A transposing read takes a 64-byte window (32 channels) out of each of 4 consecutive rows: 4 x 16 banks.  With
+  // 256-byte rows all four start in the same bank, with 128-byte rows every second one: the 16-byte pieces of a row are
+  // stored XORed with 4 * (row & 3) (resp. 4 * ((row >> 1) & 1)), which turns the four windows into a tiling of the 64
+  // banks.  (With 16 bytes of row padding instead, the windows overlapped 4-fold: 58 % of the LDS cycles were conflicts.)
+  auto row_swz = [](int r) -> int { return TW == 2 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
+  // Round 5: both tiles go global -> LDS by DMA (see conv3d_igemm_kernel).  Lane L of wave w fills bytes [16 L, 16 L + 16) of
+  // the 1 KiB that holds rows s_row + RS i (s_row = tid / PR: 64 / PR consecutive rows per wave), i.e. the PHYSICAL piece
+  // s_piece of its row; the rows of a thread share their swizzle key (RS is a multiple of 4), so it fetches one logical
+  // piece l_piece of the channel axis for all of them.
+  const int l_piece = s_piece ^ row_swz(s_row);
+  const bool co_ok = co0 + l_piece * 8 < g.Cout, ci_ok = ci0 + l_piece * 8 < g.Cin;
+  const unsigned y_col = co_ok ? static_cast<unsigned>(co0 + l_piece * 8) * 2u : 0x80000000u;
+  const unsigned x_col = ci_ok ? static_cast<unsigned>(ci0 + l_piece * 8) * 2u : 0x80000000u;
   // The source row of every voxel row of a segment is worked out ONCE per workgroup into LDS (byte offset of the shifted x
   // voxel's first channel, or an out-of-range marker for the padding): with the decomposition m -> (nb, md, mh, mw) done
   // per K step and thread, the kernel issued 12.7 VALU instructions per MFMA and was VALU-bound (profiles/r03_conv_pmc.txt).
@@ -443,31 +453,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
       xrow[m - seg_beg] = ok ? static_cast<unsigned>(((nb * g.SD + sd) * g.SH + sh) * g.SW + sw) * static_cast<unsigned>(g.Cin) * 2u : 0x80000000u;
     }
   };
-  // A transposing read takes a 64-byte window (32 channels) out of each of 4 consecutive rows: 4 x 16 banks.  With
-  // 256-byte rows all four start in the same bank, with 128-byte rows every second one: the 16-byte pieces of a row are
-  // stored XORed with 4 * (row & 3) (resp. 4 * ((row >> 1) & 1)), which turns the four windows into a tiling of the 64
-  // banks.  (With 16 bytes of row padding instead, the windows overlapped 4-fold: 58 % of the LDS cycles were conflicts.)
-  auto row_swz = [](int r) -> int { return TW == 2 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
-  u32x4 ry0[NS], rx0[NS], ry1[NS], rx1[NS];
   int seg0 = 0, seg1 = 0;                                         // rows of the current segment
-  auto load_step = [&](int m_base, u32x4 (&ry)[NS], u32x4 (&rxx)[NS]) {
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((conv_lds_void*)&lds[0][0]));
+  const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + static_cast<unsigned>(wave) * 1024u);
+  auto dma_step = [&](int m_base, int stage) {
+    const unsigned base = dst0 + static_cast<unsigned>(stage) * (2u * WK * WP);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int m = m_base + s_row + RS * i;
       const bool in = m < seg1;
       const unsigned xo = in ? xrow[m - seg0] : 0x80000000u;
       // (a marker plus the column offset stays out of range: the buffers are < 2^31 bytes)
-      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, in ? static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) * 2u + y_col : 0x80000000u, 0, 0);
-      rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + x_col, 0, 0);
-    }
-  };
-  auto store_step = [&](int stage, const u32x4 (&ry)[NS], const u32x4 (&rxx)[NS]) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      const int r = s_row + RS * i;
-      const int sp = (s_piece ^ row_swz(r)) * 16;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * WP + sp]) = ry[i];
-      *reinterpret_cast<u32x4*>(&lds[stage][WK * WP + r * WP + sp]) = rxx[i];
+      dma16(rdy, in ? static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) * 2u + y_col : 0x80000000u, base + i * (RS * WP));
+      dma16(rx, xo + x_col, base + WK * WP + i * (RS * WP));
     }
   };
   f32x16 acc[TW][TW];          // [co tile][ci tile] of the wave's quadrant
@@ -512,19 +510,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     fill_rows(seg0, seg1);
     __syncthreads();
     const int steps = (seg1 - seg0 + WK - 1) / WK;
-    load_step(seg0, ry0, rx0);
-    if (steps > 1) load_step(seg0 + WK, ry1, rx1);
-    store_step(0, ry0, rx0);
+    dma_step(seg0, 0);
+    dma_wait();
     block_barrier();
     for (int s = 0; s < steps; s += 2) {
-      if (s + 2 < steps) load_step(seg0 + (s + 2) * WK, ry0, rx0);
+      if (s + 1 < steps) dma_step(seg0 + (s + 1) * WK, 1);
       compute(0);
-      if (s + 1 < steps) store_step(1, ry1, rx1);
+      dma_wait();
       block_barrier();
       if (s + 1 >= steps) break;
-      if (s + 3 < steps) load_step(seg0 + (s + 3) * WK, ry1, rx1);
+      if (s + 2 < steps) dma_step(seg0 + (s + 2) * WK, 0);
       compute(1);
-      if (s + 2 < steps) store_step(0, ry0, rx0);
+      dma_wait();
       block_barrier();
     }
   }
