@@ -53,6 +53,25 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// 64 lanes x 16 bytes global -> LDS by DMA (buffer_load_dwordx4 ... lds): lane i lands at LDS byte dst + 16 i (dst, soff
+// wave-uniform; the K offset rides in soff).  Inline assembly: hipcc neither counts these loads nor waits for them --
+// dma_wait() before the barrier that publishes a stage does (mfma_stream.hpp explains why the builtin is not used).
+typedef __attribute__((address_space(3))) void gemm_lds_void;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned dst) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // block id -> (m tile, n tile): each XCD walks a contiguous eighth of the tiles, n fastest
 __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
   const long per = (n + 7) >> 3;
@@ -92,51 +111,37 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   constexpr int RPP = kThreads / 8;                          // rows covered per pass of the block
   constexpr int NA = BM / RPP, NB = BN / RPP;                // passes per operand tile: (4, 4) or (2, 4)
   const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + RPP i
+  // Round 5: the tiles go global -> LDS by DMA (round 2-4: through two register sets and 8 ds_write_b128 per thread and K
+  // step, 13 cycles each on the CU's store path).  Lane L of wave w fills the PHYSICAL piece s_piece of row s_row + RPP i;
+  // the swizzle key ((row >> 1) & 7) is the same for all rows of a thread (RPP is a multiple of 16), so it fetches ONE
+  // logical piece of the K step.
+  const int l_piece = s_piece ^ ((s_row >> 1) & 7);
   unsigned a_off[NA], b_off[NB];
   // a row past M / N gets an offset beyond any buffer (records < 2^31) that cannot wrap when the K offset is added
   auto tile_offsets = [&](int tm0, int tn0, unsigned (&ao)[NA], unsigned (&bo)[NB]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = s_row + RPP * i;
-      ao[i] = (tm0 + r) < M ? static_cast<unsigned>(tm0 + r) * static_cast<unsigned>(lda) * 2u + s_piece * 16u : 0x80000000u;
+      ao[i] = (tm0 + r) < M ? static_cast<unsigned>(tm0 + r) * static_cast<unsigned>(lda) * 2u + l_piece * 16u : 0x80000000u;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int r = s_row + RPP * i;
-      bo[i] = (tn0 + r) < N ? static_cast<unsigned>(tn0 + r) * static_cast<unsigned>(ldb) * 2u + s_piece * 16u : 0x80000000u;
+      bo[i] = (tn0 + r) < N ? static_cast<unsigned>(tn0 + r) * static_cast<unsigned>(ldb) * 2u + l_piece * 16u : 0x80000000u;
     }
   };
   tile_offsets(m0, n0, a_off, b_off);
-  // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 waits in the other set
-  // (one tile ahead leaves the HBM latency exposed: a K step is only ~500 cycles of MFMA per wave)
-  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  auto load_tile = [&](int kt, const unsigned (&a_off)[NA], const unsigned (&b_off)[NB], u32x4 (&ra_regs)[NA], u32x4 (&rb_regs)[NB]) {
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((gemm_lds_void*)&lds[0][0]));
+  const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + static_cast<unsigned>(wave) * 1024u);
+  auto dma_tile = [&](int kt, int stage, const unsigned (&a_off)[NA], const unsigned (&b_off)[NB]) {
     // the K offset rides in the instruction's scalar offset: no per-lane address arithmetic in the loop
-    const int kbyte = kt * BK * 2;
-    if ((kt + 1) * BK <= K) {
+    const unsigned kbyte = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(kt * BK * 2));
+    const unsigned base = __builtin_amdgcn_readfirstlane(dst0 + static_cast<unsigned>(stage) * kStageBytes);
+    const bool in_k = kt * BK + l_piece * 8 < K;             // last, partial K tile: pieces past K read as zeros (K % 8 == 0)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], kbyte, 0);
+    for (int i = 0; i < NA; ++i) dma16(ra, in_k ? a_off[i] : 0x80000000u, kbyte, base + i * (RPP * 128));
 #pragma unroll
-      for (int i = 0; i < NB; ++i) rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[i], kbyte, 0);
-    } else {                                                 // last, partial K tile: pieces past K read as zeros
-      const bool in_k = kt * BK + s_piece * 8 < K;           // K is a multiple of 8 (checked on the host)
-#pragma unroll
-      for (int i = 0; i < NA; ++i) ra_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, in_k ? a_off[i] : 0x80000000u, kbyte, 0);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) rb_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, in_k ? b_off[i] : 0x80000000u, kbyte, 0);
-    }
-  };
-  auto store_tile = [&](int stage, const u32x4 (&ra_regs)[NA], const u32x4 (&rb_regs)[NB]) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int r = s_row + RPP * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = ra_regs[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int r = s_row + RPP * i;
-      *reinterpret_cast<u32x4*>(&lds[stage][kATileBytes + r * 128 + ((s_piece ^ ((r >> 1) & 7)) << 4)]) = rb_regs[i];
-    }
+    for (int i = 0; i < NB; ++i) dma16(rb, in_k ? b_off[i] : 0x80000000u, kbyte, base + kATileBytes + i * (RPP * 128));
   };
 
   f32x16 acc[2][2];          // [n tile][m tile] of the wave's quadrant, D = [n][m]
@@ -170,10 +175,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
         for (int b = 0; b < 2; ++b) acc[a][b] = mfma<F16>(fb[a], fa[b], acc[a][b]);      // D[n][m] += W[n][k] X[m][k]
     }
   };
-  if constexpr (PERSIST) {
-    load_tile(0, a_off, b_off, ra0, rb0);
-    load_tile(1, a_off, b_off, ra1, rb1);
-  }
+  // XPRE: the first K step of the workgroup's NEXT tile is requested under the last K step of this one, into the stage
+  // that step leaves free (K steps alternate 0, 1, ..., the count is even: the last one is multiplied out of stage 1); the
+  // epilogue's row staging then lives in stage 1 alone.  (128 x 128 tiles only: 8 waves x 8 KiB do not fit one stage.)
+  constexpr bool XPRE = PERSIST && WN == 2;
+  if constexpr (XPRE) dma_tile(0, 0, a_off, b_off);
   bool first = true, has_next;
   do {
     if (!first) block_barrier();          // every wave is done with its output turn before the next tile's operands land in LDS
@@ -199,58 +205,42 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
     unsigned a_nx[NA], b_nx[NB];
     if constexpr (PERSIST) tile_offsets(m0_next, n0_next, a_nx, b_nx);
   if constexpr (KT_STATIC > 0) {
-    // K known at compile time (the token shapes: 384 and 1024): the K loop is straight-line code, so the
-    // compiler's wait counts are exact -- the ds_write of tile kt+1 waits for ITS loads only and leaves the
-    // loads of tile kt+2 in flight (across the loop back-edge of the generic form it drains them)
-    if constexpr (!PERSIST) {
-      load_tile(0, a_off, b_off, ra0, rb0);
-      if (KT_STATIC > 1) load_tile(1, a_off, b_off, ra1, rb1);
-    }
-    store_tile(0, ra0, rb0);
+    // K known at compile time (the token shapes: 384 and 1024): straight-line K loop
+    if constexpr (!XPRE) dma_tile(0, 0, a_off, b_off);
+    dma_wait();
     block_barrier();
 #pragma unroll
     for (int kt = 0; kt < KT_STATIC; ++kt) {
-      if (kt & 1) {
-        if (kt + 2 < KT_STATIC) load_tile(kt + 2, a_off, b_off, ra1, rb1);
-        else if (PERSIST && has_next) load_tile(kt + 2 - KT_STATIC, a_nx, b_nx, ra1, rb1);
-        compute(1);
-        if (kt + 1 < KT_STATIC) store_tile(0, ra0, rb0);
-      } else {
-        if (kt + 2 < KT_STATIC) load_tile(kt + 2, a_off, b_off, ra0, rb0);
-        else if (PERSIST && has_next) load_tile(kt + 2 - KT_STATIC, a_nx, b_nx, ra0, rb0);
-        compute(0);
-        if (kt + 1 < KT_STATIC) store_tile(1, ra1, rb1);
-      }
+      if (kt + 1 < KT_STATIC) dma_tile(kt + 1, (kt + 1) & 1, a_off, b_off);
+      else if (XPRE && has_next) dma_tile(0, 0, a_nx, b_nx);
+      compute(kt & 1);
+      dma_wait();
       block_barrier();
     }
   } else {
-  load_tile(0, a_off, b_off, ra0, rb0);
-  if (KT > 1) load_tile(1, a_off, b_off, ra1, rb1);
-  store_tile(0, ra0, rb0);
-  block_barrier();
-  for (int kt = 0; kt < KT; kt += 2) {
-    // even step: LDS stage 0 holds tile kt; set 0 is free, set 1 holds tile kt+1
-    if (kt + 2 < KT) load_tile(kt + 2, a_off, b_off, ra0, rb0);
-    compute(0);
-    if (kt + 1 < KT) store_tile(1, ra1, rb1);
+    dma_tile(0, 0, a_off, b_off);
+    dma_wait();
     block_barrier();
-    if (kt + 1 >= KT) break;
-    // odd step: stage 1 holds tile kt+1; set 1 is free, set 0 holds tile kt+2
-    if (kt + 3 < KT) load_tile(kt + 3, a_off, b_off, ra1, rb1);
-    compute(1);
-    if (kt + 2 < KT) store_tile(0, ra0, rb0);
-    block_barrier();
-  }
+    for (int kt = 0; kt < KT; kt += 2) {
+      if (kt + 1 < KT) dma_tile(kt + 1, 1, a_off, b_off);
+      compute(0);
+      dma_wait();
+      block_barrier();
+      if (kt + 1 >= KT) break;
+      if (kt + 2 < KT) dma_tile(kt + 2, 0, a_off, b_off);
+      compute(1);
+      dma_wait();
+      block_barrier();
+    }
   }
 
   // epilogue.  A lane holds token m = .. + fr, outputs n = .. + 8 q + 4 kg + (0..3): stored straight from the
   // registers that would be 8-byte pieces scattered over 64 rows per instruction.  The wave's 64 x 64 tile goes
   // through its own LDS region instead (row pitch padded by 16 bytes against bank conflicts) and leaves as
   // whole rows: 16 bytes per lane, 8 (4 for fp32) consecutive rows of 128 (256) contiguous bytes per store.
-  constexpr int ELT = OUT_F32 ? 4 : 2;
-  constexpr int PITCH = 64 * ELT + 16;
-  unsigned char* stage = &lds[0][0] + wave * (64 * PITCH);
-  static_assert(2 * WN * 64 * (64 * 2 + 16) <= 2 * kStageBytes, "bf16 staging fits");
+  // Rows of 128 bytes without padding (4 waves x 8 KiB = one stage), the 16-byte pieces XORed with row & 7.
+  unsigned char* stage = &lds[XPRE ? 1 : 0][0] + wave * (64 * 128);
+  static_assert(2 * WN * 64 * 128 <= (XPRE ? 1 : 2) * kStageBytes, "bf16 staging fits");
   // (the main loop's last barrier has passed: every wave is done reading the operand tiles)
   if constexpr (!OUT_F32) {
 #pragma unroll
@@ -268,7 +258,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
             if (RELU) v = fmaxf(v, 0.f);
             h[e] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
           }
-          *reinterpret_cast<uint2*>(stage + (b * 32 + fr) * PITCH + nl * 2) =
+          *reinterpret_cast<uint2*>(stage + (b * 32 + fr) * 128 + ((((nl >> 2) >> 1) ^ (fr & 7)) << 4) + ((nl >> 2) & 1) * 8) =
               uint2{static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16), static_cast<unsigned>(h[2]) | (static_cast<unsigned>(h[3]) << 16)};
         }
     // same wave wrote and reads: LDS operations of a wave are in order
@@ -278,7 +268,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
       const int row = it * 8 + r0;
       const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + piece * 8;
       if (m < M && n < N) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + piece * 16);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((piece ^ (row & 7)) << 4));
         unsigned short* dst = static_cast<unsigned short*>(Cout) + static_cast<long>(m) * ldc + n;
         if (n + 8 <= N && (ldc & 7) == 0) *reinterpret_cast<u32x4*>(dst) = v;
         else {
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
         }
     }
   }
-    // on to the workgroup's next tile (its first two K steps are already in the register sets)
+    // on to the workgroup's next tile (XPRE: its first K step is already on its way into stage 0)
     if constexpr (PERSIST) {
       t = t_next; m0 = m0_next; n0 = n0_next;
 #pragma unroll
