@@ -29,6 +29,7 @@ LIBS = {
     "libtransoar_gemm.so": ["gemm.hip", "gemm_stream.hip"],
     "libtransoar_convgemm.so": ["conv_gemm.hip"],
     "libtransoar_attn.so": ["attn.hip"],
+    "libtransoar_optim.so": ["optim.hip"],
 }
 
 

@@ -32,9 +32,12 @@ def build_optimizer(model, config, fused=None, capturable=False):
     if capturable:
         dev = (backbone + rest)[0].device
         lr, lr_backbone = torch.tensor(lr, device=dev), torch.tensor(lr_backbone, device=dev)
-    return torch.optim.AdamW(
-        [{"params": backbone}, {"params": rest, "lr": lr}],
-        lr=lr_backbone, weight_decay=float(config["weight_decay"]), fused=fused, capturable=capturable)
+    groups = [{"params": backbone}, {"params": rest, "lr": lr}]
+    if fused and os.environ.get("TRANSOAR_TORCH_ADAMW", "0") != "1" and all(p.dtype == torch.float32 for p in backbone + rest):
+        # the whole update in one launch (transoar_amd/optim.py); torch.optim.AdamW's state and schedulers as they are
+        from .optim import FlatAdamW
+        return FlatAdamW(groups, lr=lr_backbone, weight_decay=float(config["weight_decay"]))
+    return torch.optim.AdamW(groups, lr=lr_backbone, weight_decay=float(config["weight_decay"]), fused=fused, capturable=capturable)
 
 
 class TrainStep:
@@ -189,6 +192,8 @@ class TrainStep:
             raise RuntimeError("HIP was initialised with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: this ROCm's pre-recorded "
                                "graph packets corrupt the replayed step (DESIGN.md section 8); export "
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process, or call transoar_amd.use_safe_graph_replay() before the first HIP call")
+        if self.capture_optimizer and hasattr(self.optimizer, "prepare_capture"):
+            self.optimizer.prepare_capture()
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
