@@ -62,10 +62,10 @@ def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
 
 
 BWD_KINDS = ("bwd_query", "cell_count", "scan", "cell_fill", "pull", "value_tile", "value_cells", "bwd_generic")
-PMC_FILE = "r04_msda_pmc.json"
+PMC_FILE = "r05_msda_pmc_step.json"
 # the backward as the training step runs it (round 4: transoar_msda3d_backward_proj, bf16 grad_proj instead of fp32
 # grad_loc / grad_attn): FETCH_SIZE / WRITE_SIZE passes of `tools/bench_msda.py --proj`
-PMC_BWD_FILE = "r04_msda_pmc_proj.json"
+PMC_BWD_FILE = "r05_msda_pmc_step.json"
 
 
 def pmc_traffic(kind, dims):
@@ -386,7 +386,7 @@ def main():
             gbps = b / kernels["fwd"]["avg_ms"] / 1e6
             roofline = {"kernel": "msda3d_fwd_pcm", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic("fwd", dims),
-                        "traffic_unit": "MB per launch (PMC, profiles/%s: collected on the op bench's jittered locations, not on the step's launches)" % PMC_FILE,
+                        "traffic_unit": "MB per launch (PMC, profiles/%s: collected on the launches of this training step, eager mode)" % PMC_FILE,
                         "avg_launch_ms": kernels["fwd"]["avg_ms"], "algorithmic_MB": round(b / 1e6, 1), "timing": timing}
         chain = [k for k in BWD_KINDS if k in kernels]
         if chain:                               # one backward call = the chain of these kernels, against B_bwd
@@ -395,7 +395,7 @@ def main():
             b = msda_algorithmic_bytes("bwd", **dims)
             msda_bwd = {"kernels": chain, "ms_per_call": round(ms_call, 4), "algorithmic_MB": round(b / 1e6, 1),
                         "achieved_GBps": round(b / ms_call / 1e6, 1), "frac": round(b / ms_call / 1e6 / HBM_PEAK_GBPS, 4),
-                        "traffic": pmc_traffic("bwd", dims), "traffic_unit": "MB per call (PMC, profiles/%s)" % PMC_BWD_FILE}
+                        "traffic": pmc_traffic("bwd", dims), "traffic_unit": "MB per call (PMC, profiles/%s: the training step's own launches)" % PMC_BWD_FILE}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
