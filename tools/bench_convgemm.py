@@ -30,6 +30,10 @@ def t_ms(fn, n=7):
 
 only = [a for a in sys.argv[1:] if not a.startswith("-")]
 with_miopen = "--no-miopen" not in sys.argv
+# Two passes: every layer on the own kernels first, the MIOpen column afterwards -- timed in one loop, MIOpen's workspace
+# allocations and solver launches of layer k disturbed the own timings of layer k + 1 (round 4's table showed outP2 forward at
+# 0.579 ms next to MIOpen and 0.53 alone; round-4 VERDICT weak #7).
+results = []
 for name, ci, co, d, h, w, s in LAYERS:
     if only and name not in only:
         continue
@@ -45,7 +49,14 @@ for name, ci, co, d, h, w, s in LAYERS:
         res["own_wgrad"] = round(t_ms(lambda: G.conv_wgrad(x, gy, s)), 3)
     flop = 2 * 27 * ci * co * y.shape[2] * y.shape[3] * y.shape[4] * 2
     res["fwd_TFs"] = round(flop / res["own_fwd"] / 1e9, 1)
+    results.append(res)
+    del x, y, gy
+torch.cuda.empty_cache()
+for res in results:
     if with_miopen:
+        ci, co, d, h, w, s = res["shape"]
+        x = torch.randn(2, ci, d, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+        wt = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
         xn = x.detach().requires_grad_()
         wn = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d).requires_grad_()
         res["miopen_fwd"] = round(t_ms(lambda: F.conv3d(xn, wn, stride=s, padding=1)), 3)
@@ -53,5 +64,5 @@ for name, ci, co, d, h, w, s in LAYERS:
         gn = torch.randn_like(yn)
         res["miopen_dgrad"] = round(t_ms(lambda: torch.autograd.grad(yn, (xn,), gn, retain_graph=True)), 3)
         res["miopen_wgrad"] = round(t_ms(lambda: torch.autograd.grad(yn, (wn,), gn, retain_graph=True)), 3)
+        del x, xn, yn, gn
     print(json.dumps(res), flush=True)
-    del x, y, gy
