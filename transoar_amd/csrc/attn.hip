@@ -538,6 +538,32 @@ template <int HD> struct WinTile {
     if (HD == 16 && ((lane >> 4) & 1)) f = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     return f;
   }
+  // the same in two halves (global -> registers, registers -> LDS): the backward fetches the NEXT window's tiles while it
+  // works on this one
+  struct Regs { u32x4 a, b; };
+  static __device__ __forceinline__ Regs fetch(const unsigned short* __restrict__ src, long tok_elems, int n) {
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    Regs r{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if (row < n) {
+      if constexpr (HD == 32) {
+        const u32x4* g = reinterpret_cast<const u32x4*>(src + row * tok_elems + 16 * half);
+        r.a = g[0];
+        r.b = g[1];
+      } else {
+        r.a = *reinterpret_cast<const u32x4*>(src + row * tok_elems + 8 * half);
+      }
+    }
+    return r;
+  }
+  static __device__ __forceinline__ void put(unsigned char* tile, const Regs& r) {
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    if constexpr (HD == 32) {
+      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half)) = r.a;
+      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half + 1)) = r.b;
+    } else {
+      *reinterpret_cast<u32x4*>(tile + off(row, half)) = r.a;
+    }
+  }
   // one (window, head) slice [n tokens][HD] of a token matrix (tokens `tok_elems` elements apart) -> LDS tile;
   // rows >= n are zero.  256 threads: thread = (row, half of the row)
   static __device__ __forceinline__ void load(const unsigned short* __restrict__ src, long tok_elems, int n, unsigned char* tile) {
@@ -699,30 +725,57 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
 #pragma unroll
     for (int r = 0; r < 16; ++r) db[t][r] = 0.f;
 
-  for (int w = blockIdx.x; w < windows; w += gridDim.x) {
+  // Everything a window needs from global memory is requested one window ahead (round 5): the four operand tiles as
+  // 16 / 32 bytes per thread, and per row the out / dout pieces of D = rowsum(dout o out), the log-sum-exp and the mask
+  // bits.  With one 96-KiB workgroup per CU nothing else covers that latency -- it was a quarter of a window's time.
+  struct WinPre {
+    typename T::Regs q, k, v, d;
+    u32x4 o4[HD / 16], d4[HD / 16], mw;
+    float lse;
+  };
+  auto fetch_window = [&](int w) {
+    WinPre pf;
     const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
-    T::load(base, tok, n, qt);
-    T::load(base + heads * HD, tok, n, kt);
-    T::load(base + 2 * heads * HD, tok, n, vt);
-    T::load(dout + static_cast<long>(w) * n * C + head * HD, C, n, dt);
-    // D = rowsum(dout o out) of row i (this lane: half of the head's channels), the row's log-sum-exp, its mask bits
-    float dpart = 0.f;
+    pf.q = T::fetch(base, tok, n);
+    pf.k = T::fetch(base + heads * HD, tok, n);
+    pf.v = T::fetch(base + 2 * heads * HD, tok, n);
+    pf.d = T::fetch(dout + static_cast<long>(w) * n * C + head * HD, C, n);
+    pf.mw = u32x4{0u, 0u, 0u, 0u};
+    pf.lse = INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) { pf.o4[ks] = u32x4{0u, 0u, 0u, 0u}; pf.d4[ks] = u32x4{0u, 0u, 0u, 0u}; }
     if (row_ok) {
       const unsigned short* orow = out + (static_cast<long>(w) * n + i) * C + head * HD;
       const unsigned short* drow = dout + (static_cast<long>(w) * n + i) * C + head * HD;
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
-        const u32x4 o4 = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * kh);
-        const u32x4 d4 = *reinterpret_cast<const u32x4*>(drow + 16 * ks + 8 * kh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dpart += bf16_lo(o4[e]) * bf16_lo(d4[e]) + bf16_hi(o4[e]) * bf16_hi(d4[e]);
+        pf.o4[ks] = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * kh);
+        pf.d4[ks] = *reinterpret_cast<const u32x4*>(drow + 16 * ks + 8 * kh);
       }
+      pf.lse = lse2[(static_cast<long>(w) * heads + head) * n + i];
+      if (maskbits != nullptr) pf.mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
     }
+    return pf;
+  };
+  WinPre pre;
+  if (static_cast<int>(blockIdx.x) < windows) pre = fetch_window(blockIdx.x);
+  for (int w = blockIdx.x; w < windows; w += gridDim.x) {
+    T::put(qt, pre.q);
+    T::put(kt, pre.k);
+    T::put(vt, pre.v);
+    T::put(dt, pre.d);
+    // D = rowsum(dout o out) of row i (this lane: half of the head's channels), the row's log-sum-exp, its mask bits
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dpart += bf16_lo(pre.o4[ks][e]) * bf16_lo(pre.d4[ks][e]) + bf16_hi(pre.o4[ks][e]) * bf16_hi(pre.d4[ks][e]);
     const float dsum = dpart + other_half(dpart);
-    const float lse_i = row_ok ? lse2[(static_cast<long>(w) * heads + head) * n + i] : INFINITY;
-    u32x4 mw{0u, 0u, 0u, 0u};
-    if (maskbits != nullptr && row_ok) mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
+    const float lse_i = pre.lse;
+    const u32x4 mw = pre.mw;
     __syncthreads();
+    if (w + static_cast<int>(gridDim.x) < windows) pre = fetch_window(w + gridDim.x);
 
     // ---- row side: P, dS of the wave's 32 rows; dq; P and scale dS -> LDS
     s16x8 qf[HD / 16], df[HD / 16];
