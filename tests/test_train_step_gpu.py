@@ -275,6 +275,9 @@ def test_captured_data_parallel_step():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()           # the child needs ~60 GB of the same GPU; this process may be caching most of it by now
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
