@@ -208,8 +208,10 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
         const bool ok = on && sq >= 0;
         const unsigned loff = (ok && loc_piece) ? item * item_loc + r * 16 : 0xfffffff0u;
         const unsigned aoff = (ok && !loc_piece) ? item * item_attn + (r - 12) * 16 : 0xfffffff0u;
-        const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(lrs, loff, 0, 0);
-        const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 0);
+        // (aux = 2: the non-temporal hint.  Locations, weights and the output rows pass through once; without the hint
+        // they push value rows out of the XCD's L2: HBM fetch 512 -> 457 MB per launch, round 5)
+        const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(lrs, loff, 0, 2);
+        const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 2);
         *reinterpret_cast<u32x4*>(vbuf + qq * kPcmPU + r * 16) = loc_piece ? vl : va;
       }
     }
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
     const u32x4 line = *reinterpret_cast<const u32x4*>(vbuf + (lane >> 3) * 128 + (lane & 7) * 16);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, static_cast<int>(value_bytes), 0x00020000);
     const unsigned ooff = sq >= 0 ? (__umul24(static_cast<unsigned>(sq), static_cast<unsigned>(M)) + m) * (C * sizeof(VT)) + (lane & 7) * 16u : 0xfffffff0u;
-    __builtin_amdgcn_raw_buffer_store_b128(line, ors, ooff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(line, ors, ooff, 0, 2);
   }
 }
 
