@@ -56,7 +56,8 @@ int transoar_roi_attn_backward(const void* q, const void* k, const void* v, cons
  *   out      (windows, n, heads * 32) bf16;  lse2 (windows, heads, n) fp32: log2-sum-exp2 of the rows (for the backward)
  * backward: dqkv (windows, n, 3, heads, 32) bf16 fully written; dbias (heads, n, 128) fp32 is ACCUMULATED into
  * (the caller zeroes it): the sum of dS over the windows.
- * n <= 128, head dimension 16 or 32 (`32` in the shapes above stands for it).
+ * n <= 128, head dimension 16 or 32 (`32` in the shapes above stands for it), scale > 0 (the row maximum is taken over
+ * the unscaled scores); anything else returns TRANSOAR_ATTN_ERR_DIM.
  */
 int transoar_win_attn_forward(const void* qkv, const float* bias, const unsigned* maskbits, void* out, float* lse2,
                               int windows, int n_win, int n, int heads, int head_dim, float scale, void* hip_stream);

@@ -9,7 +9,7 @@ from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, vi
 from transoar_amd.matcher import DenseTargets
 from transoar_amd.train_step import TrainStep
 from transoar_amd.transoarnet import TransoarNet, build_criterion
-cfg = visceral_config(refine=True, use_cuda=True); cfg["bbox_properties"] = synthetic_bbox_properties(20)
+cfg = visceral_config(refine="--no-refine" not in sys.argv, use_cuda=True, swin="--swin" in sys.argv); cfg["bbox_properties"] = synthetic_bbox_properties(20)
 torch.manual_seed(0)
 model = TransoarNet(cfg).cuda(); step = TrainStep(model, build_criterion(cfg), cfg, graph=False)
 x = torch.rand(2, 1, 160, 160, 256, device="cuda")

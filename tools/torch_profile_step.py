@@ -15,7 +15,7 @@ from transoar_amd.matcher import DenseTargets  # noqa: E402
 from transoar_amd.train_step import TrainStep  # noqa: E402
 from transoar_amd.transoarnet import TransoarNet, build_criterion  # noqa: E402
 
-cfg = visceral_config(refine=True, use_cuda=True)
+cfg = visceral_config(refine="--no-refine" not in sys.argv, use_cuda=True, swin="--swin" in sys.argv)
 cfg["bbox_properties"] = synthetic_bbox_properties(20)
 torch.manual_seed(0)
 model = TransoarNet(cfg).cuda()

@@ -584,19 +584,27 @@ template <int HD> struct WinTile {
     }
   }
 };
+// The P / dS tiles keep the 8-byte pieces of row i at piece ^ ((i >> 1) & 7) (round 5): the 16 rows of a ds_write_b64 lane group then
+// cover the 32 store banks once (at pitch 320 alone rows i and i + 2 shared their banks: 8-way, 71 % of the kernel's LDS
+// cycles were conflict cycles), and the 4 rows x 8 pieces of a transposing read still tile the 64 read banks (the XOR
+// permutes the 8 pieces inside a row's 64-byte window).
+__device__ __forceinline__ int win_p_swz(int row) { return (row >> 1) & 7; }
 // a [row][key] tile (pitch kWinPPitch) as the MFMA B operand [k = rows R0 + 8 kh .. + 7][n = key K0 + (lane & 31)]
 __device__ __forceinline__ s16x8 wp_frag(const unsigned char* tile, int lane, int R0, int K0) {
   const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
-  const unsigned char* a = tile + (R0 + 8 * kh + r) * kWinPPitch + 2 * K0 + 32 * g + 8 * c;
-  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
-  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * kWinPPitch));
+  const int row = R0 + 8 * kh + r, piece = (K0 >> 2) + 4 * g + c;            // 8-byte piece of the row, swizzled like the stores
+  const unsigned char* a0 = tile + row * kWinPPitch + ((piece ^ win_p_swz(row)) << 3);
+  const unsigned char* a1 = tile + (row + 4) * kWinPPitch + ((piece ^ win_p_swz(row + 4)) << 3);
+  const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+  const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
   return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// scores of the wave's 32 rows against key tile t, in log2 units, masked: lane = (row i, half kh), entry r = key
-// 32 t + (r & 3) + 8 (r >> 2) + 4 kh
-__device__ __forceinline__ void win_scores(const f32x16& sT, int t, int kh, int n, float scale2, const float* __restrict__ bias_row,
-                                           unsigned mask_word, bool row_ok, float (&s2)[16]) {
+// Accumulator the score MFMAs of key tile t start from (round 5): bias / scale, so that scale2 * (k.q + init) is the
+// score in log2 units with ONE fma per entry -- and -inf where the key is padding (K's padding rows are zero: the entry
+// stays -inf).  lane = (row i, half kh), entry r = key 32 t + (r & 3) + 8 (r >> 2) + 4 kh.
+__device__ __forceinline__ void win_bias_init(const float* __restrict__ bias_row, int t, int kh, int n, float inv_scale, bool row_ok,
+                                              f32x16& c) {
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int key0 = 32 * t + 8 * qd + 4 * kh;
@@ -604,14 +612,23 @@ __device__ __forceinline__ void win_scores(const f32x16& sT, int t, int kh, int 
     if (row_ok) b4 = *reinterpret_cast<const float4*>(bias_row + key0);
     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = 4 * qd + e;
-      const bool differ = (mask_word >> (8 * qd + 4 * kh + e)) & 1u;
-      float v = sT[r] * scale2 + (bb[e] + (differ ? -100.f : 0.f)) * kLog2e;
-      s2[r] = (key0 + e < n) ? v : -INFINITY;
+    for (int e = 0; e < 4; ++e) c[4 * qd + e] = bb[e] * inv_scale;
+    if (32 * t + 8 * qd + 8 > n) {                       // wave-uniform: only the group that holds key n .. pays for the test
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (key0 + e >= n) c[4 * qd + e] = -INFINITY;
     }
   }
 }
+// ... plus the shifted-window mask (-100 where the region labels differ) of a tile that has any: neg = -100 / scale
+__device__ __forceinline__ void win_mask_apply(unsigned mask_word, int kh, float neg, f32x16& c) {
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((mask_word >> (8 * qd + 4 * kh + e)) & 1u) c[4 * qd + e] += neg;
+}
+__device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
 // the wave's 32 x HD result (channel (r & 3) + 8 (r >> 2) + 4 kh of row / key `lane & 31`) -> 8-byte pieces of a token row
 template <int HD>
 __device__ __forceinline__ void win_store(unsigned short* __restrict__ dst, const f32x16& acc, int kh) {
@@ -621,78 +638,105 @@ __device__ __forceinline__ void win_store(unsigned short* __restrict__ dst, cons
         u32x2{pack_bf16(acc[4 * qd], acc[4 * qd + 1]), pack_bf16(acc[4 * qd + 2], acc[4 * qd + 3])};
 }
 
-// forward: grid (windows, heads)
+// forward: grid (persistent workgroups, heads); workgroup x walks the windows x, x + gridDim.x, ... of its head (round 5:
+// as one workgroup per (window, head) a wave lived 25 000 cycles and waited 78 % of them -- three dependent round trips
+// (K / V / q, bias, store) with three short workgroups per CU to cover them).  Now the next window's K, V, q and mask
+// bits are requested before this window's arithmetic, K / V tiles are double-buffered in LDS (one barrier per
+// window), and the head's bias rows -- the same for every window -- stay in registers.
 template <int HD>
-__global__ __launch_bounds__(256) void win_attn_fwd(
+__global__ __launch_bounds__(256, 2) void win_attn_fwd(
     const unsigned short* __restrict__ qkv, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
-    unsigned short* __restrict__ out, float* __restrict__ lse2, int n, int heads, int n_win, float scale) {
+    unsigned short* __restrict__ out, float* __restrict__ lse2, int n, int heads, int n_win, int windows, float scale) {
   using T = WinTile<HD>;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * T::kBytes];
-  unsigned char* kt = lds;
-  unsigned char* vt = lds + T::kBytes;
-  const int w = blockIdx.x, head = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * T::kBytes];         // (K, V) x 2 stages
+  const int head = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int kh = lane >> 5;
   const long tok = 3L * heads * HD;                                       // elements per token of qkv
-  const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
-  T::load(base + heads * HD, tok, n, kt);
-  T::load(base + 2 * heads * HD, tok, n, vt);
   const int i = wave * 32 + (lane & 31);
   const bool row_ok = i < n;
-  s16x8 qf[HD / 16];
-#pragma unroll
-  for (int ks = 0; ks < HD / 16; ++ks) {
-    u32x4 x{0u, 0u, 0u, 0u};
-    if (row_ok) x = *reinterpret_cast<const u32x4*>(base + i * tok + 16 * ks + 8 * kh);
-    qf[ks] = __builtin_bit_cast(s16x8, x);
-  }
-  u32x4 mw{0u, 0u, 0u, 0u};
-  if (maskbits != nullptr && row_ok) mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
+  const bool wave_live = wave * 32 < n;                 // a wave without a live row (n <= 96) only helps to stage the tiles
+  const float scale2 = scale * kLog2e, inv_scale = 1.f / scale, neg = -100.f * inv_scale;
   const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
-  __syncthreads();
-  if (wave * 32 >= n) return;                          // no live row in this wave (n <= 96)
+  f32x16 cb[4];                                         // bias / scale, -inf at padding keys: what the score MFMAs start from
+#pragma unroll
+  for (int t = 0; t < 4; ++t) win_bias_init(bias_row, t, kh, n, inv_scale, row_ok, cb[t]);
 
-  const float scale2 = scale * kLog2e;
-  float s2[4][16];
-  float m = -INFINITY;
+  struct WinPre {
+    typename T::Regs k, v;
+    u32x4 q[HD / 16], mw;
+  };
+  auto fetch_window = [&](int w) {
+    WinPre pf;
+    const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
+    pf.k = T::fetch(base + heads * HD, tok, n);
+    pf.v = T::fetch(base + 2 * heads * HD, tok, n);
+    pf.mw = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    f32x16 sT;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sT[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) sT = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT);
-    win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2[t]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, s2[t][r]);
-  }
-  m = fmaxf(m, other_half(m));
-  float l = 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s2[t][r] = fast_exp2(s2[t][r] - m);
-      l += s2[t][r];
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      pf.q[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (row_ok) pf.q[ks] = *reinterpret_cast<const u32x4*>(base + i * tok + 16 * ks + 8 * kh);
     }
-  l += other_half(l);
-  const float inv = 1.f / l;
-  f32x16 acc;
+    if (maskbits != nullptr && row_ok) pf.mw = *reinterpret_cast<const u32x4*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4);
+    return pf;
+  };
+  WinPre pre;
+  if (static_cast<int>(blockIdx.x) < windows) pre = fetch_window(blockIdx.x);
+  int stage = 0;
+  for (int w = blockIdx.x; w < windows; w += gridDim.x, stage ^= 1) {
+    unsigned char* kt = lds + stage * 2 * T::kBytes;
+    unsigned char* vt = kt + T::kBytes;
+    T::put(kt, pre.k);
+    T::put(vt, pre.v);
+    s16x8 qf[HD / 16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = __builtin_bit_cast(s16x8, pre.q[ks]);
+    const u32x4 mw = pre.mw;
+    // one barrier per window: a wave that runs ahead writes the OTHER stage, and cannot reach this one again before every
+    // wave has passed the next barrier, i.e. has finished reading it
+    __syncthreads();
+    if (w + static_cast<int>(gridDim.x) < windows) pre = fetch_window(w + gridDim.x);
+    if (!wave_live) continue;
+
+    f32x16 sT[4];                                        // raw scores k.q + bias / scale: log2 units = scale2 * sT (scale > 0)
+    float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    float p[16];
+    for (int t = 0; t < 4; ++t) {
+      sT[t] = cb[t];
+      if (maskbits != nullptr && wave_any(mw[t] != 0u)) win_mask_apply(mw[t], kh, neg, sT[t]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = s2[t][r] * inv;
-    s16x8 pf[2];
-    column_to_b_frags(p, pf);
+      for (int ks = 0; ks < HD / 16; ++ks) sT[t] = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT[t]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc = mfma(T::cols(vt, lane, 32 * t + 16 * j), pf[j], acc);
-  }
-  if (row_ok) {
-    win_store<HD>(out + (static_cast<long>(w) * n + i) * (heads * HD) + head * HD, acc, kh);
-    if (kh == 0) lse2[(static_cast<long>(w) * heads + head) * n + i] = m + log2f(l);
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sT[t][r]);
+    }
+    m = fmaxf(m, other_half(m));
+    const float m2 = m * scale2;
+    float l = 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // P stays unnormalised (<= 1) on its way through the matrix cores; the row's 1 / l scales the 32 x HD result
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = fast_exp2(__builtin_fmaf(sT[t][r], scale2, -m2));
+        l += p[r];
+      }
+      s16x8 pf[2];
+      column_to_b_frags(p, pf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc = mfma(T::cols(vt, lane, 32 * t + 16 * j), pf[j], acc);
+    }
+    l += other_half(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= inv;
+    if (row_ok) {
+      win_store<HD>(out + (static_cast<long>(w) * n + i) * (heads * HD) + head * HD, acc, kh);
+      if (kh == 0) lse2[(static_cast<long>(w) * heads + head) * n + i] = m2 + log2f(l);
+    }
   }
 }
 
@@ -719,11 +763,15 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
   const bool row_ok = i < n;
   const float scale2 = scale * kLog2e;
   const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
-  float db[4][16];                                               // bias gradient of (row i, this lane's 64 keys), summed over the windows
+  const float inv_scale = 1.f / scale, neg = -100.f * inv_scale;
+  float db[4][16];                                               // scale * bias gradient of (row i, this lane's 64 keys), summed over the windows
+  f32x16 cb[4];                                                  // bias / scale (-inf at padding keys): what the score MFMAs start from, the same for every window
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t) {
+    win_bias_init(bias_row, t, kh, n, inv_scale, row_ok, cb[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) db[t][r] = 0.f;
+  }
 
   // Everything a window needs from global memory is requested one window ahead (round 5): the four operand tiles as
   // 16 / 32 bytes per thread, and per row the out / dout pieces of D = rowsum(dout o out), the log-sum-exp and the mask
@@ -771,7 +819,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         dpart += bf16_lo(pre.o4[ks][e]) * bf16_lo(pre.d4[ks][e]) + bf16_hi(pre.o4[ks][e]) * bf16_hi(pre.d4[ks][e]);
-    const float dsum = dpart + other_half(dpart);
+    const float dsum_s = (dpart + other_half(dpart)) * scale;
     const float lse_i = pre.lse;
     const u32x4 mw = pre.mw;
     __syncthreads();
@@ -789,16 +837,15 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x16 sT, dpT;
+      f32x16 sT = cb[t], dpT;
+      if (maskbits != nullptr && wave_any(mw[t] != 0u)) win_mask_apply(mw[t], kh, neg, sT);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) dpT[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
         sT = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT);
         dpT = mfma(T::rows(vt, lane, 32 * t, ks), df[ks], dpT);
       }
-      float s2[16];
-      win_scores(sT, t, kh, n, scale2, bias_row, mw[t], row_ok, s2);
       unsigned ppk[8], dpk[8];
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) {
@@ -806,10 +853,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int r = 2 * e2 + e;
-          pr[e] = fast_exp2(s2[r] - lse_i);                       // padding rows: lse = +inf -> 0; keys >= n: s2 = -inf -> 0
-          const float ds = pr[e] * (dpT[r] - dsum);
-          db[t][r] += ds;
-          dsr[e] = ds * scale;
+          pr[e] = fast_exp2(__builtin_fmaf(sT[r], scale2, -lse_i));      // padding rows: lse = +inf -> 0; keys >= n: sT = -inf -> 0
+          dsr[e] = pr[e] * __builtin_fmaf(dpT[r], scale, -dsum_s);       // scale * dS = scale * P (dP - D)
+          db[t][r] += dsr[e];
         }
         ppk[e2] = pack_bf16(pr[0], pr[1]);
         dpk[e2] = pack_bf16(dsr[0], dsr[1]);
@@ -817,7 +863,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
       // entries 4 qd .. 4 qd + 3 = keys 32 t + 8 qd + 4 kh .. + 3: 8 bytes of the row's P / dS line
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const int off = i * kWinPPitch + 2 * (32 * t + 8 * qd + 4 * kh);
+        const int off = i * kWinPPitch + (((8 * t + 2 * qd + kh) ^ win_p_swz(i)) << 3);
         *reinterpret_cast<u32x2*>(pt + off) = u32x2{ppk[2 * qd], ppk[2 * qd + 1]};
         *reinterpret_cast<u32x2*>(st + off) = u32x2{dpk[2 * qd], dpk[2 * qd + 1]};
       }
@@ -854,7 +900,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (key < n) atomicAdd(drow + key, db[t][r]);
+        if (key < n) atomicAdd(drow + key, db[t][r] * inv_scale);
       }
   }
 }
@@ -941,12 +987,14 @@ extern "C" int transoar_roi_attn_backward(const void* q, const void* k, const vo
 extern "C" int transoar_win_attn_forward(const void* qkv, const float* bias, const unsigned* maskbits, void* out, float* lse2, int windows,
                                          int n_win, int n, int heads, int head_dim, float scale, void* hip_stream) {
   if (!qkv || !bias || !out || !lse2) return TRANSOAR_ATTN_ERR_NULL;
-  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0 || !(scale > 0.f)) return TRANSOAR_ATTN_ERR_DIM;
   auto qs = static_cast<const unsigned short*>(qkv);
   auto os = static_cast<unsigned short*>(out);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (head_dim == 32) hipLaunchKernelGGL(win_attn_fwd<32>, dim3(windows, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, scale);
-  else hipLaunchKernelGGL(win_attn_fwd<16>, dim3(windows, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, scale);
+  // two resident workgroups per CU (<= 256 registers, 16 / 32 KiB of LDS), the windows of a head dealt round-robin
+  const int per_head = std::max(1, std::min(windows, 512 / std::min(heads, 512)));
+  if (head_dim == 32) hipLaunchKernelGGL(win_attn_fwd<32>, dim3(per_head, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, windows, scale);
+  else hipLaunchKernelGGL(win_attn_fwd<16>, dim3(per_head, heads), dim3(256), 0, st, qs, bias, maskbits, os, lse2, n, heads, n_win, windows, scale);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -954,7 +1002,7 @@ extern "C" int transoar_win_attn_backward(const void* qkv, const void* out, cons
                                           const unsigned* maskbits, void* dqkv, float* dbias, int windows, int n_win, int n, int heads,
                                           int head_dim, float scale, void* hip_stream) {
   if (!qkv || !out || !dout || !lse2 || !bias || !dqkv || !dbias) return TRANSOAR_ATTN_ERR_NULL;
-  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0) return TRANSOAR_ATTN_ERR_DIM;
+  if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0 || !(scale > 0.f)) return TRANSOAR_ATTN_ERR_DIM;
   // one resident set of workgroups (~100 KiB of LDS: one per CU), the windows of a head dealt round-robin
   const int per_head = std::max(1, std::min(windows, 256 / std::min(heads, 256)));
   auto qs = static_cast<const unsigned short*>(qkv);

@@ -110,12 +110,12 @@ class _WindowLayout:
         inv = torch.empty(n_tok + 1, dtype=torch.long)
         inv[src] = torch.arange(src.numel())
         self.scatter = inv[:n_tok].to(device)
-        # the same two lists for the row kernel (int32) and the list each one's adjoint gathers through: the partition
-        # reads rows 0 .. n_tok (n_tok = the zero row, whose gradient is dropped: -1), the merge reads the slots, of which
-        # the padding slots are referenced by no token (-1)
-        self.gather32, self.scatter32 = self.gather.int(), self.scatter.int()
-        self.gather_back = torch.cat((inv[:n_tok], inv.new_full((1,), -1))).int().to(device)
-        self.scatter_back = torch.where(src < n_tok, src, torch.full_like(src, -1)).int().to(device)
+        # the same two lists for the row kernel (int32; -1 = a zero row: the padding slots, so that no padding token has to be
+        # appended to the token matrix) and the list each one's adjoint gathers through: the partition's adjoint is the merge
+        # list, the merge's adjoint the partition list (padding slots are referenced by no token: -1 again)
+        self.scatter32 = self.scatter.int()
+        self.gather32 = torch.where(src < n_tok, src, torch.full_like(src, -1)).int().to(device)
+        self.gather_back, self.scatter_back = self.scatter32, self.gather32
         self.mask = None
         self.mask_bits = None
         if any(s > 0 for s in shift):
@@ -221,8 +221,7 @@ class SwinBlock(nn.Module):
         if _fast(x) and (c * 2) % 16 == 0:
             # bf16 tokens (what the qkv projection rounds them to anyway) through the row kernels both ways
             y = _norm16(x, self.norm1)
-            y = torch.cat((y, y.new_zeros((b, 1, c))), dim=1)                                                  # row n_tok: the padding token
-            y = _Rows.apply(y, lay.gather32, lay.gather_back).view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition
+            y = _Rows.apply(y, lay.gather32, lay.gather_back).view(b, lay.n_windows, lay.n_per, c)           # pad (zero rows) + shift + partition
             y = self.attn(y, lay.mask, lay.mask_bits)
             y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, lay.scatter_back)                # merge + shift back + crop
             x = x + self.drop_path(y)
