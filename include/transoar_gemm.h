@@ -30,6 +30,18 @@ enum {
 int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                      int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream);
 /*
+ * transoar_gemm_nt (bf16 in, bf16 out) with the exact GELU of the Swin blocks' MLP in its epilogue (reference:
+ * backbones/encoder_blocks.py Mlp: fc2(act(fc1(x))), act = nn.GELU; forward and backward of `act` fused into the products
+ * on either side of it).  `aux` (M, N) bf16 has C's leading dimension.
+ *   TRANSOAR_GEMM_GELU_FORWARD:   aux = h = A B^T + bias (written),  C = gelu(h)            -- fc1 + act
+ *   TRANSOAR_GEMM_GELU_BACKWARD:  C = (A B^T) * gelu'(aux)           (aux = h, read)        -- act's backward on fc2's data gradient
+ * Both apply the activation to the bf16-rounded product, in fp32 (Phi(x) to 1.5e-7 absolute): the rounding points of the
+ * separate kernels they replace.
+ */
+enum { TRANSOAR_GEMM_GELU_FORWARD = 1, TRANSOAR_GEMM_GELU_BACKWARD = 2 };
+int transoar_gemm_nt_gelu(const void* A, const void* B, const float* bias, void* C, void* aux, int M, int N, int K, int lda,
+                          int ldb, int ldc, int mode, void* hip_stream);
+/*
  * The same product for the two shape classes of the refinement block, dense operands (leading dimension = row length),
  * bf16 in and out, register-stationary / tile-streaming kernels (csrc/gemm_stream.hip):
  *   transoar_gemm_k384:  C (M, N) = A (M, 384) . B (N, 384)^T (+ bias) (ReLU);  N a multiple of 64

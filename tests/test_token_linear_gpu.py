@@ -120,3 +120,34 @@ def test_ffn_with_hidden_width_384_takes_the_unfused_path():
     assert (y.float() - ref).abs().max() <= 2.0 ** -5 * ref.abs().max()
     y.float().sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad.float()).all() and lin1.weight.grad is not None
+
+
+@pytest.mark.parametrize("tokens,c,hidden", [(2 * 10000 + 37, 48, 192), (9000, 96, 384), (8200, 192, 776)])
+def test_gelu_mlp_matches_the_unfused_chain(tokens, c, hidden):
+    """fc2(gelu(fc1(x))) with the activation in the GEMM epilogues (token_linear._GeluMlp, transoar_gemm_nt_gelu) against the same
+    two GEMMs with torch's gelu between them: the epilogues apply the activation to the bf16-rounded product in fp32 (Phi(x) to
+    1.5e-7), so values and gradients agree to an ulp of the bf16 results.  192 / 776 hidden channels: a partial last column tile."""
+    from transoar_amd.token_linear import gelu_mlp, gelu_mlp_usable, token_linear
+    torch.manual_seed(1)
+    fc1, fc2 = torch.nn.Linear(c, hidden).cuda(), torch.nn.Linear(hidden, c).cuda()
+    x = torch.randn(1, tokens, c, device="cuda").to(torch.bfloat16)
+    gy = torch.randn(1, tokens, c, device="cuda", dtype=torch.bfloat16)
+    res = []
+    for fused in (False, True):
+        xi = x.clone().requires_grad_(True)
+        fc1.zero_grad(); fc2.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                assert gelu_mlp_usable(xi, fc1, fc2, 8192)
+                y = gelu_mlp(xi, fc1, fc2)
+            else:
+                hid = torch.nn.functional.gelu(token_linear(xi, fc1.weight, fc1.bias, force_hip=True, min_tokens=8192))
+                y = token_linear(hid, fc2.weight, fc2.bias, force_hip=True, min_tokens=8192)
+        y.backward(gy)
+        res.append((y.float(), xi.grad.float(), fc1.weight.grad.clone(), fc1.bias.grad.clone(), fc2.weight.grad.clone(),
+                    fc2.bias.grad.clone()))
+    for name, a, b in zip(("y", "gx", "gw1", "gb1", "gw2", "gb2"), res[0], res[1]):
+        tol = 2.0 ** -7 if name in ("y", "gx") else 2e-3          # one bf16 ulp of the largest value / sums of ~1e4 such terms
+        assert (a - b).abs().max().item() <= tol * a.abs().max().item(), name
+    frac = (res[0][0] != res[1][0]).float().mean().item()
+    assert frac <= 0.05, frac          # ... and nearly all outputs are bit-identical

@@ -510,7 +510,7 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
 // ds_read_b128 operand fragments, and a transposing read's four rows still tile the 64 banks.
 // ===========================================================================
 constexpr int kWinN = 128;                 // tokens of a window, padded
-constexpr int kWinPPitch = 320;            // bytes per row of the P / dS tiles (256 + 64: four rows of a transposing read tile the banks)
+constexpr int kWinPPitch = 256;            // bytes per row of the P / dS tiles: no padding, the 8-byte pieces of a row are swizzled (win_p_swz)
 
 // Tiles [128 rows][HD channels] bf16, HD = 16 or 32 (the shipped configurations have 16: 48 / 96 / 192 / 384 channels
 // with 3 / 6 / 12 / 24 heads, config/attn_fpn_*: encoder stage k works at the width of stage k - 1's output).  A row's
@@ -584,11 +584,13 @@ template <int HD> struct WinTile {
     }
   }
 };
-// The P / dS tiles keep the 8-byte pieces of row i at piece ^ ((i >> 1) & 7) (round 5): the 16 rows of a ds_write_b64 lane group then
-// cover the 32 store banks once (at pitch 320 alone rows i and i + 2 shared their banks: 8-way, 71 % of the kernel's LDS
-// cycles were conflict cycles), and the 4 rows x 8 pieces of a transposing read still tile the 64 read banks (the XOR
-// permutes the 8 pieces inside a row's 64-byte window).
-__device__ __forceinline__ int win_p_swz(int row) { return (row >> 1) & 7; }
+// The P / dS tiles [128 rows][128 keys] bf16 keep the 32 8-byte pieces of row i at piece ^ win_p_swz(i) (round 5; they had a
+// 320-byte pitch: rows i and i + 2 of a ds_write_b64 lane group shared their banks, 71 % of the kernel's LDS cycles were
+// conflict cycles -- and 96 KiB per workgroup).  Bits 4:3 of the swizzle are the row's two low bits: the four rows of a
+// transposing read (4 rows x 8 pieces per 32-lane group) land in four different 64-byte windows and tile the 64 read
+// banks; its low four bits take all 16 values over the 16 rows of a store's lane group, which then covers the 32 store
+// banks once.
+__device__ __forceinline__ int win_p_swz(int row) { return ((row & 3) << 3) | (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 // a [row][key] tile (pitch kWinPPitch) as the MFMA B operand [k = rows R0 + 8 kh .. + 7][n = key K0 + (lane & 31)]
 __device__ __forceinline__ s16x8 wp_frag(const unsigned char* tile, int lane, int R0, int K0) {
   const int kh = lane >> 5, r = (lane & 15) >> 2, g = (lane >> 4) & 1, c = lane & 3;
@@ -765,10 +767,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
   const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
   const float inv_scale = 1.f / scale, neg = -100.f * inv_scale;
   float db[4][16];                                               // scale * bias gradient of (row i, this lane's 64 keys), summed over the windows
-  f32x16 cb[4];                                                  // bias / scale (-inf at padding keys): what the score MFMAs start from, the same for every window
+  // bias / scale (-inf at padding keys): what the score MFMAs start from, the same for every window.  (Two 80-KiB workgroups
+  // per CU would fit the LDS since the P / dS tiles lost their padding, but not the register file: at 256 registers --
+  // without these 64 -- hipcc spills 81 and the kernel takes 1.8 x as long.)
+  constexpr bool kKeepBias = true;
+  f32x16 cb[kKeepBias ? 4 : 1];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    win_bias_init(bias_row, t, kh, n, inv_scale, row_ok, cb[t]);
+    if constexpr (kKeepBias) win_bias_init(bias_row, t, kh, n, inv_scale, row_ok, cb[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) db[t][r] = 0.f;
   }
@@ -837,7 +843,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x16 sT = cb[t], dpT;
+      f32x16 sT, dpT;
+      if constexpr (kKeepBias) sT = cb[t];
+      else win_bias_init(bias_row, t, kh, n, inv_scale, row_ok, sT);
       if (maskbits != nullptr && wave_any(mw[t] != 0u)) win_mask_apply(mw[t], kh, neg, sT);
 #pragma unroll
       for (int r = 0; r < 16; ++r) dpT[r] = 0.f;
@@ -1003,7 +1011,7 @@ extern "C" int transoar_win_attn_backward(const void* qkv, const void* out, cons
                                           int head_dim, float scale, void* hip_stream) {
   if (!qkv || !out || !dout || !lse2 || !bias || !dqkv || !dbias) return TRANSOAR_ATTN_ERR_NULL;
   if ((head_dim != 16 && head_dim != 32) || n <= 0 || n > kWinN || heads <= 0 || heads > 65535 || windows <= 0 || n_win <= 0 || !(scale > 0.f)) return TRANSOAR_ATTN_ERR_DIM;
-  // one resident set of workgroups (~100 KiB of LDS: one per CU), the windows of a head dealt round-robin
+  // one resident set of workgroups (80 / 96 KiB of LDS and > 256 registers: one per CU), the windows of a head dealt round-robin
   const int per_head = std::max(1, std::min(windows, 256 / std::min(heads, 256)));
   auto qs = static_cast<const unsigned short*>(qkv);
   auto os = static_cast<const unsigned short*>(out);

@@ -47,6 +47,34 @@ __device__ __forceinline__ unsigned short f32_to_f16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));
 }
 
+__device__ __forceinline__ float bf16_lo_f(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// The exact GELU (approximate='none') and its derivative in fp32.  Phi(x) through erfc's rational-exponential form
+// (Abramowitz & Stegun 7.1.26: |error| <= 1.5e-7 -- four orders below the bf16 rounding of the result) on the quarter-rate
+// rcp / exp2 units: 0.5 erfc(|x| / sqrt 2) = 0.5 t (a1 + t (a2 + ...)) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2), and the SAME
+// exponential is the density's.  (erff + expf of the device library: ~100 instructions per element with two waves per SIMD
+// to hide them -- the fused products ran 0.9 ms per step SLOWER than the separate gelu kernels they replaced.)
+__device__ __forceinline__ float gelu_phi(float x, float& u) {            // -> Phi(x); u = exp(-x^2 / 2)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+  const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);            // -0.5 log2(e)
+  const float half = 0.5f * poly * u;
+  return x < 0.f ? half : 1.f - half;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float u;
+  return x * gelu_phi(x, u);
+}
+__device__ __forceinline__ float gelu_grad_f(float dy, float x) {
+  float u;
+  const float cdf = gelu_phi(x, u);
+  return dy * __builtin_fmaf(x, u * 0.39894228040143267794f, cdf);          // Phi + x phi
+}
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+  return static_cast<unsigned>(f32_to_bf16(a)) | (static_cast<unsigned>(f32_to_bf16(b)) << 16);
+}
+
 // LDS-only barrier: __syncthreads() carries a workgroup fence that also drains the outstanding GLOBAL loads
 // (s_waitcnt vmcnt(0)), i.e. the prefetch of the next tiles, at every K step.  Here: LDS traffic done, then barrier.
 __device__ __forceinline__ void block_barrier() {
@@ -79,10 +107,16 @@ __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
   return swz < n ? swz : -1;
 }
 
-template <bool F16, bool OUT_F32, bool RELU, int KT_STATIC, int WN>
+// EPI: 0 plain, 1 ReLU, 2 GELU with both results (C = gelu(h), aux = h = A B^T + bias: what the backward needs), 3 the GELU's
+// backward on the way out (C = (A B^T) * gelu'(aux)).  2 and 3 work on the bf16-ROUNDED product, in the row-store phase: the
+// rounding points of a GEMM followed by torch's gelu / gelu_backward kernels, minus their passes over the hidden tensor.
+template <bool F16, bool OUT_F32, int EPI, int KT_STATIC, int WN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles, int tiles_n) {
+    void* __restrict__ Cout, unsigned short* __restrict__ aux, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles,
+    int tiles_n) {
+  constexpr bool RELU = EPI == 1;
+  static_assert(EPI < 2 || (!F16 && !OUT_F32), "the GELU epilogues are bf16 in, bf16 out");
   constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (2 or 4), 2 along M
   constexpr int kStageBytes = kATileBytes + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][kStageBytes];      // [stage]: A tile, then B tile
@@ -91,7 +125,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   // tile per workgroup; with the static K loops the host launches ~2 workgroups per CU (PERSIST) and the loads of the
   // NEXT tile's first two K steps are issued under the last two K steps of this one: the 2-3 us of load latency at the
   // head of every tile -- a third of a six-step K loop -- disappear behind the previous tile's MFMAs and epilogue.
-  constexpr bool PERSIST = KT_STATIC > 0 && (KT_STATIC % 2) == 0;
+  // DPRE (round 5, second half): the run-time K loop does the same with ONE step of look-ahead and a stage index that is
+  // carried from tile to tile -- the Swin stages' products have K = 48 .. 192, i.e. one to three K steps per tile, and ran
+  // one workgroup per tile: load latency, a handful of MFMAs, epilogue, nothing overlapping.
+  constexpr bool DPRE = KT_STATIC == 0 && WN == 2;
+  constexpr bool PERSIST = (KT_STATIC > 0 && (KT_STATIC % 2) == 0) || DPRE;
   const long per = (n_tiles + 7) >> 3;
   const long xend = min((static_cast<long>(blockIdx.x & 7) + 1) * per, n_tiles);
   const long G = gridDim.x >> 3;
@@ -159,8 +197,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
       fb_off[ks][i] = rn * 128 + ((piece ^ ((rn >> 1) & 7)) << 4);
     }
   auto compute = [&](int stage) {
-    const unsigned char* ta = lds[stage];
-    const unsigned char* tb = lds[stage] + kATileBytes;
+    const unsigned char* ta = &lds[0][0] + stage * kStageBytes;
+    const unsigned char* tb = ta + kATileBytes;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s16x8 fa[2], fb[2];
@@ -178,8 +216,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   // XPRE: the first K step of the workgroup's NEXT tile is requested under the last K step of this one, into the stage
   // that step leaves free (K steps alternate 0, 1, ..., the count is even: the last one is multiplied out of stage 1); the
   // epilogue's row staging then lives in stage 1 alone.  (128 x 128 tiles only: 8 waves x 8 KiB do not fit one stage.)
-  constexpr bool XPRE = PERSIST && WN == 2;
-  if constexpr (XPRE) dma_tile(0, 0, a_off, b_off);
+  constexpr bool XPRE = PERSIST && WN == 2 && !DPRE;
+  if constexpr (XPRE || DPRE) dma_tile(0, 0, a_off, b_off);
+  u32x4 hpre[EPI == 3 ? 8 : 1];
+  int cur = 0;                            // DPRE: the stage that receives K step 0 of the current tile
+  int last = 0;                           //       ... and the one its last K step was multiplied out of (the epilogue stages rows there)
   bool first = true, has_next;
   do {
     if (!first) block_barrier();          // every wave is done with its output turn before the next tile's operands land in LDS
@@ -217,6 +258,27 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
       dma_wait();
       block_barrier();
     }
+  } else if constexpr (DPRE) {
+    dma_wait();                            // K step 0 of this tile (requested under the previous tile's last step) has landed
+    block_barrier();
+    if constexpr (EPI == 3) {              // the GELU input of the lane's 8 output pieces: in flight under the K loop and the staging
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wm * 64 + it * 8 + (lane >> 3), n = n0 + wn * 64 + (lane & 7) * 8;
+        hpre[it] = u32x4{0u, 0u, 0u, 0u};
+        if (m < M && n + 8 <= N && (ldc & 7) == 0) hpre[it] = *reinterpret_cast<const u32x4*>(aux + static_cast<long>(m) * ldc + n);
+      }
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+      const int sg = cur ^ (kt & 1);
+      if (kt + 1 < KT) dma_tile(kt + 1, sg ^ 1, a_off, b_off);
+      else if (has_next) dma_tile(0, sg ^ 1, a_nx, b_nx);      // stage sg ^ 1: last read two barriers ago (K step / previous epilogue)
+      compute(sg);
+      if (kt + 1 < KT) dma_wait();          // (the next tile's step is waited for at the top of its own turn, not here)
+      block_barrier();
+    }
+    last = cur ^ ((KT - 1) & 1);
+    cur = last ^ 1;
   } else {
     dma_tile(0, 0, a_off, b_off);
     dma_wait();
@@ -239,8 +301,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   // through its own LDS region instead (row pitch padded by 16 bytes against bank conflicts) and leaves as
   // whole rows: 16 bytes per lane, 8 (4 for fp32) consecutive rows of 128 (256) contiguous bytes per store.
   // Rows of 128 bytes without padding (4 waves x 8 KiB = one stage), the 16-byte pieces XORed with row & 7.
-  unsigned char* stage = &lds[XPRE ? 1 : 0][0] + wave * (64 * 128);
-  static_assert(2 * WN * 64 * 128 <= (XPRE ? 1 : 2) * kStageBytes, "bf16 staging fits");
+  unsigned char* stage = &lds[0][0] + (DPRE ? last : (XPRE ? 1 : 0)) * kStageBytes + wave * (64 * 128);
+  static_assert(2 * WN * 64 * 128 <= ((XPRE || DPRE) ? 1 : 2) * kStageBytes, "bf16 staging fits");
   // (the main loop's last barrier has passed: every wave is done reading the operand tiles)
   if constexpr (!OUT_F32) {
 #pragma unroll
@@ -268,13 +330,34 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
       const int row = it * 8 + r0;
       const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + piece * 8;
       if (m < M && n < N) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((piece ^ (row & 7)) << 4));
-        unsigned short* dst = static_cast<unsigned short*>(Cout) + static_cast<long>(m) * ldc + n;
-        if (n + 8 <= N && (ldc & 7) == 0) *reinterpret_cast<u32x4*>(dst) = v;
-        else {
-          *reinterpret_cast<uint2*>(dst) = uint2{v[0], v[1]};            // N is a multiple of 4
-          if (n + 4 < N) *reinterpret_cast<uint2*>(dst + 4) = uint2{v[2], v[3]};
+        u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((piece ^ (row & 7)) << 4));
+        const long at = static_cast<long>(m) * ldc + n;
+        const bool whole = n + 8 <= N && (ldc & 7) == 0;
+        auto put = [&](unsigned short* dst, const u32x4& x) {
+          if (whole) *reinterpret_cast<u32x4*>(dst) = x;
+          else {
+            *reinterpret_cast<uint2*>(dst) = uint2{x[0], x[1]};            // N is a multiple of 4
+            if (n + 4 < N) *reinterpret_cast<uint2*>(dst + 4) = uint2{x[2], x[3]};
+          }
+        };
+        if constexpr (EPI == 2) {
+          put(aux + at, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack2_bf16(gelu_f(bf16_lo_f(v[e])), gelu_f(bf16_hi_f(v[e])));
         }
+        if constexpr (EPI == 3) {
+          u32x4 h{0u, 0u, 0u, 0u};
+          if (whole) h = DPRE ? hpre[it] : *reinterpret_cast<const u32x4*>(aux + at);
+          else {
+            const uint2 h0 = *reinterpret_cast<const uint2*>(aux + at);
+            h[0] = h0.x; h[1] = h0.y;
+            if (n + 4 < N) { const uint2 h1 = *reinterpret_cast<const uint2*>(aux + at + 4); h[2] = h1.x; h[3] = h1.y; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = pack2_bf16(gelu_grad_f(bf16_lo_f(v[e]), bf16_lo_f(h[e])), gelu_grad_f(bf16_hi_f(v[e]), bf16_hi_f(h[e])));
+        }
+        put(static_cast<unsigned short*>(Cout) + at, v);
       }
     }
   } else {
@@ -311,42 +394,48 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
 }
 
 template <bool F16, bool OUT_F32>
-int launch(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc, int relu,
-           hipStream_t st) {
+int launch(const void* A, const void* B, const float* bias, void* C, void* aux, int M, int N, int K, int lda, int ldb, int ldc,
+           int epi, hipStream_t st) {
   // the 128 x 256 tile (8 waves, half the re-reads of the activation rows) measured SLOWER on 234000 x 384 -> 1024
   // (0.41 vs 0.38 ms: one 96-KiB block per CU) -- kept as a template instance, not selected
   const bool wide = false;
   const int BN = wide ? 256 : 128;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const long n_tiles = static_cast<long>(tiles_m) * tiles_n;
-  const int kts = K == 384 ? 6 : (K == 1024 ? 16 : 0);
+  const int kts = epi >= 2 ? 0 : (K == 384 ? 6 : (K == 1024 ? 16 : 0));       // the GELU epilogues: dynamic K loop only
   // static K loops: persistent workgroups, two per CU (TRANSOAR_GEMM_PERSIST_WGS, 0 = one workgroup per tile)
   static const long persist_wgs = [] {
     const char* e = getenv("TRANSOAR_GEMM_PERSIST_WGS");
     return e ? atol(e) : 512L;
   }();
   long per_xcd = (n_tiles + 7) / 8;
-  if (kts > 0 && persist_wgs >= 8 && per_xcd > persist_wgs / 8) per_xcd = persist_wgs / 8;
+  if ((kts > 0 || !wide) && persist_wgs >= 8 && per_xcd > persist_wgs / 8) per_xcd = persist_wgs / 8;
   const dim3 grid(static_cast<unsigned>(per_xcd * 8));
   auto a = static_cast<const unsigned short*>(A);
   auto b = static_cast<const unsigned short*>(B);
-#define TRANSOAR_GEMM_LAUNCH(R, KTS)                                                                                        \
+  auto x = static_cast<unsigned short*>(aux);
+#define TRANSOAR_GEMM_LAUNCH(E, KTS)                                                                                        \
   do {                                                                                                                      \
     if (wide)                                                                                                               \
-      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS, 4>), grid, dim3(512), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
+      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, E, KTS, 4>), grid, dim3(512), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, \
                          ldc, n_tiles, tiles_n);                                                                            \
     else                                                                                                                    \
-      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, R, KTS, 2>), grid, dim3(256), 0, st, a, b, bias, C, M, N, K, lda, ldb, \
+      hipLaunchKernelGGL((gemm_nt_kernel<F16, OUT_F32, E, KTS, 2>), grid, dim3(256), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, \
                          ldc, n_tiles, tiles_n);                                                                            \
   } while (0)
-  if (relu) {
-    if (kts == 6) TRANSOAR_GEMM_LAUNCH(true, 6);
-    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(true, 16);
-    else TRANSOAR_GEMM_LAUNCH(true, 0);
+  if constexpr (!F16 && !OUT_F32) {
+    if (epi == 2) { TRANSOAR_GEMM_LAUNCH(2, 0); return static_cast<int>(hipGetLastError()); }
+    if (epi == 3) { TRANSOAR_GEMM_LAUNCH(3, 0); return static_cast<int>(hipGetLastError()); }
+  }
+  if (epi >= 2) return TRANSOAR_GEMM_ERR_DTYPE;
+  if (epi == 1) {
+    if (kts == 6) TRANSOAR_GEMM_LAUNCH(1, 6);
+    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(1, 16);
+    else TRANSOAR_GEMM_LAUNCH(1, 0);
   } else {
-    if (kts == 6) TRANSOAR_GEMM_LAUNCH(false, 6);
-    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(false, 16);
-    else TRANSOAR_GEMM_LAUNCH(false, 0);
+    if (kts == 6) TRANSOAR_GEMM_LAUNCH(0, 6);
+    else if (kts == 16) TRANSOAR_GEMM_LAUNCH(0, 16);
+    else TRANSOAR_GEMM_LAUNCH(0, 0);
   }
 #undef TRANSOAR_GEMM_LAUNCH
   return static_cast<int>(hipGetLastError());
@@ -354,21 +443,37 @@ int launch(const void* A, const void* B, const float* bias, void* C, int M, int 
 
 }  // namespace
 
-extern "C" int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda,
-                                int ldb, int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream) {
+static int check_nt(const void* A, const void* B, const float* bias, const void* C, int M, int N, int K, int lda, int ldb, int ldc) {
   if (!A || !B || !C) return TRANSOAR_GEMM_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7) || (ldc & 3))
     return TRANSOAR_GEMM_ERR_DIM;
   if (static_cast<long>(N) * ldb * 2 >= 0x7ffffff0L || static_cast<long>(M) * lda * 2 >= 0x7ffffff0L) return TRANSOAR_GEMM_ERR_DIM;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15u) return TRANSOAR_GEMM_ERR_ALIGN;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const bool f16 = in_dtype == TRANSOAR_GEMM_F16;
-  if (in_dtype != TRANSOAR_GEMM_BF16 && !f16) return TRANSOAR_GEMM_ERR_DTYPE;
-  if (out_dtype == TRANSOAR_GEMM_F32) return f16 ? launch<true, true>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st)
-                                                 : launch<false, true>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st);
-  if (out_dtype != in_dtype) return TRANSOAR_GEMM_ERR_DTYPE;
-  return f16 ? launch<true, false>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st)
-             : launch<false, false>(A, B, bias, C, M, N, K, lda, ldb, ldc, relu, st);
+  return 0;
 }
 
-extern "C" int transoar_gemm_abi_version(void) { return 3; }
+extern "C" int transoar_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int in_dtype, int out_dtype, int relu, void* hip_stream) {
+  if (const int rc = check_nt(A, B, bias, C, M, N, K, lda, ldb, ldc)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const bool f16 = in_dtype == TRANSOAR_GEMM_F16;
+  const int epi = relu ? 1 : 0;
+  if (in_dtype != TRANSOAR_GEMM_BF16 && !f16) return TRANSOAR_GEMM_ERR_DTYPE;
+  if (out_dtype == TRANSOAR_GEMM_F32) return f16 ? launch<true, true>(A, B, bias, C, nullptr, M, N, K, lda, ldb, ldc, epi, st)
+                                                 : launch<false, true>(A, B, bias, C, nullptr, M, N, K, lda, ldb, ldc, epi, st);
+  if (out_dtype != in_dtype) return TRANSOAR_GEMM_ERR_DTYPE;
+  return f16 ? launch<true, false>(A, B, bias, C, nullptr, M, N, K, lda, ldb, ldc, epi, st)
+             : launch<false, false>(A, B, bias, C, nullptr, M, N, K, lda, ldb, ldc, epi, st);
+}
+
+extern "C" int transoar_gemm_nt_gelu(const void* A, const void* B, const float* bias, void* C, void* aux, int M, int N, int K,
+                                     int lda, int ldb, int ldc, int mode, void* hip_stream) {
+  if (!aux) return TRANSOAR_GEMM_ERR_NULL;
+  if (const int rc = check_nt(A, B, bias, C, M, N, K, lda, ldb, ldc)) return rc;
+  if (reinterpret_cast<uintptr_t>(aux) & 15u) return TRANSOAR_GEMM_ERR_ALIGN;
+  if (mode != TRANSOAR_GEMM_GELU_FORWARD && mode != TRANSOAR_GEMM_GELU_BACKWARD) return TRANSOAR_GEMM_ERR_DIM;
+  return launch<false, false>(A, B, bias, C, aux, M, N, K, lda, ldb, ldc, mode == TRANSOAR_GEMM_GELU_FORWARD ? 2 : 3,
+                              static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int transoar_gemm_abi_version(void) { return 4; }

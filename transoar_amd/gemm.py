@@ -10,7 +10,7 @@ from . import _native  # noqa: F401  (torch's HIP runtime first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG, "libtransoar_gemm.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 STREAM_SQUARE = os.environ.get("TRANSOAR_GEMM_STREAM_SQUARE", "0") == "1"
 STREAM_N384 = os.environ.get("TRANSOAR_GEMM_N384", "0") == "1"
 STREAM = os.environ.get("TRANSOAR_GEMM_STREAM", "1") != "0"      # the K = 384 / N = 384 streaming kernels (csrc/gemm_stream.hip)
@@ -24,6 +24,8 @@ def _load():
     i, p = ctypes.c_int, ctypes.c_void_p
     lib.transoar_gemm_nt.restype = i
     lib.transoar_gemm_nt.argtypes = [p, p, p, p] + [i] * 9 + [p]
+    lib.transoar_gemm_nt_gelu.restype = i
+    lib.transoar_gemm_nt_gelu.argtypes = [p, p, p, p, p] + [i] * 7 + [p]
     lib.transoar_gemm_k384.restype = i
     lib.transoar_gemm_k384.argtypes = [p, p, p, p, i, i, i, p]
     lib.transoar_gemm_k384_drop.restype = i
@@ -109,6 +111,46 @@ def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
                                   torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("transoar_gemm_nt failed with code %d" % rc)
+    return out
+
+
+def gelu_usable(x, w):
+    """bf16 operands of `linear_nt` whose (M, N) result the GELU epilogues can address (byte offsets fit 31 bits)."""
+    return usable(x, w) and x.dtype == torch.bfloat16 and x.shape[0] * w.shape[0] * 2 < 0x7ffffff0
+
+
+def linear_gelu(x, w, bias=None):
+    """-> (h, gelu(h)), h = x @ w.T + bias, both bf16 (M, N): fc1 and the activation of an MLP in one kernel
+    (transoar_gemm_nt_gelu, TRANSOAR_GEMM_GELU_FORWARD)."""
+    if not gelu_usable(x, w):
+        raise RuntimeError("transoar_gemm_nt_gelu: operands must be 2-D row-major bf16 CUDA tensors with K % 8 == 0, N % 4 == 0")
+    m, k = x.shape
+    n = w.shape[0]
+    h = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    a = torch.empty_like(h)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_gemm_nt_gelu(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), a.data_ptr(), h.data_ptr(),
+                                       m, n, k, x.stride(0), w.stride(0), n, 1, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_nt_gelu failed with code %d" % rc)
+    return h, a
+
+
+def linear_gelu_grad(gy, wt, h):
+    """-> (gy @ wt.T) * gelu'(h), bf16 (M, N): the data gradient of the layer AFTER a GELU with the activation's backward in the
+    epilogue (TRANSOAR_GEMM_GELU_BACKWARD).  gy (M, K), wt (N, K) = that layer's weight transposed, h (M, N) the GELU's input."""
+    if not gelu_usable(gy, wt) or h.dtype != torch.bfloat16 or not h.is_contiguous() or tuple(h.shape) != (gy.shape[0], wt.shape[0]):
+        raise RuntimeError("transoar_gemm_nt_gelu: bf16 row-major operands, h (M, N) contiguous")
+    m, k = gy.shape
+    n = wt.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=gy.device)
+    with torch.cuda.device(gy.device):
+        rc = lib.transoar_gemm_nt_gelu(gy.data_ptr(), wt.data_ptr(), None, out.data_ptr(), h.data_ptr(), m, n, k, gy.stride(0),
+                                       wt.stride(0), n, 2, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_gemm_nt_gelu failed with code %d" % rc)
     return out
 
 

@@ -27,7 +27,7 @@ from torch import nn
 
 from . import rows, win_attn
 from . import tokens as fused_tokens
-from .token_linear import token_linear
+from .token_linear import gelu_mlp, gelu_mlp_usable, token_linear
 
 MIN_TOKENS = 8192            # token matrices at least this tall take the hand-written GEMMs (token_linear)
 
@@ -195,6 +195,10 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        no_drop = not self.training or self.drop.p == 0.0
+        if (_fast(x) and no_drop and isinstance(self.act, nn.GELU) and self.act.approximate == "none"
+                and gelu_mlp_usable(x, self.fc1, self.fc2, MIN_TOKENS)):
+            return gelu_mlp(x, self.fc1, self.fc2)          # the activation rides in the two GEMMs' epilogues
         if _fast(x):
             hid = self.act(token_linear(x, self.fc1.weight, self.fc1.bias, force_hip=True, min_tokens=MIN_TOKENS))
             return self.drop(token_linear(self.drop(hid), self.fc2.weight, self.fc2.bias, force_hip=True, min_tokens=MIN_TOKENS))

@@ -254,6 +254,62 @@ def fused_ffn(x, linear1, linear2, dropout):
     return _FusedFFN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, seed, 1.0 - dropout.p if active else 1.0)
 
 
+class _GeluMlp(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) of a Swin block (encoder_blocks.py Mlp) as ONE autograd node on the tiled GEMM, the activation in the
+    epilogues on either side of it: forward = fc1 with (h, gelu(h)) out + fc2; backward
+        gh = (gy W2) * gelu'(h)        one GEMM (gemm.linear_gelu_grad)        gW2, gb2 = gy^T a, sum gy
+        gx = gh W1                                                              gW1, gb1 = gh^T x, sum gh
+    -- torch's gelu / gelu_backward kernels (read h, write a; read ga and h, write gh: 3.1 GB per stage-0 block) are gone, and
+    the arithmetic is theirs (fp32 on the bf16-rounded products)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        xb = x.to(torch.bfloat16)
+        w1b, w2b = shadow.bf16_or_cast(w1), shadow.bf16_or_cast(w2)
+        x2 = xb.reshape(-1, xb.shape[-1])
+        h, a = gemm.linear_gelu(x2, w1b, b1)
+        out = gemm.linear_nt(a, w2b, b2)
+        ctx.save_for_backward(xb, w1b, w2b, h, a)
+        shadow.stamp(ctx)
+        ctx.in_dtype = x.dtype
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        return out.view(*xb.shape[:-1], w2b.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        shadow.check(ctx)
+        xb, w1b, w2b, h, a = ctx.saved_tensors
+        gy2 = gy.to(torch.bfloat16).reshape(-1, gy.shape[-1]).contiguous()
+        x2 = xb.reshape(-1, xb.shape[-1])
+        need = ctx.needs_input_grad
+        gx = None
+        with torch.autocast("cuda", enabled=False):
+            gh = gemm.linear_gelu_grad(gy2, w2b.t().contiguous(), h)
+            gw2, gb2 = weight_bias_grad(gy2, a, need[3], ctx.has_b2 and need[4])
+            if need[0]:
+                gx = gemm.linear_nt(gh, w1b.t().contiguous()).view(xb.shape).to(ctx.in_dtype)
+            gw1, gb1 = weight_bias_grad(gh, x2, need[1], ctx.has_b1 and need[2])
+        return gx, gw1, gb1, gw2, gb2
+
+
+GELU_MLP = os.environ.get("TRANSOAR_GELU_MLP", "1") != "0"
+
+
+def gelu_mlp_usable(x, fc1, fc2, min_tokens=None):
+    """bf16 autocast on the GPU, fp32 parameters, enough tokens, shapes the tiled GEMM and its GELU epilogues take."""
+    tokens = x.numel() // x.shape[-1]
+    k, hid, n = fc1.weight.shape[1], fc1.weight.shape[0], fc2.weight.shape[0]
+    return (GELU_MLP and x.is_cuda and tokens >= (MIN_TOKENS if min_tokens is None else min_tokens) and x.is_contiguous()
+            and fc1.weight.dtype == torch.float32 and fc2.weight.dtype == torch.float32 and fc2.weight.shape[1] == hid
+            and k % 8 == 0 and hid % 8 == 0 and n % 8 == 0 and tokens * max(hid, k, n) * 2 < 0x7ffffff0
+            and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+
+
+def gelu_mlp(x, fc1, fc2):
+    """fc2(gelu(fc1(x))) (exact GELU, no dropout between the layers)."""
+    return _GeluMlp.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+
+
 def token_linear(x, weight, bias=None, force_hip=False, min_tokens=None, weight2=None):
     """F.linear for (…, T, K) token tensors; the chunked-wgrad path applies to
     bf16 autocast on the GPU with enough tokens, the stock one otherwise.  force_hip: the hand-written GEMM for
