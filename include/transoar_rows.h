@@ -16,6 +16,13 @@ extern "C" {
 int transoar_rows_gather(const void* src, const int* index, void* out, int B, long S, long K,
                          int row_bytes, void* hip_stream);
 
+/* bf16 rows: out[b][k][:] = resid[b][k][:] + scale[b] * src[b][index[k]][:]  (fp32 arithmetic, one rounding).  The Swin block's
+ * window merge + residual + stochastic-depth factor in one pass (reference: backbones/encoder_blocks.py, SwinTransformerBlock3D
+ * forward: `x = shortcut + self.drop_path(x)` after window_reverse / roll / crop).  scale (B,) fp32 or NULL (= 1), resid (B,K,row)
+ * dense or NULL (= 0); index < 0 reads a zero row. */
+int transoar_rows_gather_axpy(const void* src, const int* index, const float* scale, const void* resid, void* out,
+                              int B, long S, long K, int row_bytes, void* hip_stream);
+
 /* out[b][s][:] = sum_{i in [inv_ptr[s], inv_ptr[s+1])} g[b][inv_idx[i]][:]   (fp32 or bf16 rows,
  * fp32 accumulation); inv_ptr int32 (S+1), inv_idx int32: the CSR inverse of `index`. */
 int transoar_rows_pull_sum(const void* g, const int* inv_ptr, const int* inv_idx, void* out, int B,

@@ -25,6 +25,37 @@ __global__ __launch_bounds__(256) void rows_gather(const u32x4r* __restrict__ sr
   out[(b * K + k) * vec_per_row + v] = s < 0 ? u32x4r{0u, 0u, 0u, 0u} : src[(b * S + s) * vec_per_row + v];
 }
 
+// out[b][k] = resid[b][k] + scale[b] * src[b][index[k]] on bf16 rows (fp32 arithmetic, one rounding): the Swin block's window
+// merge with its residual add and the per-sample stochastic-depth factor in the gather's own pass (resid / scale may be null:
+// the adjoint is the same gather through the inverse list, scaled, without a residual).
+__global__ __launch_bounds__(256) void rows_gather_axpy(const u32x4r* __restrict__ src, const int* __restrict__ index,
+                                                        const float* __restrict__ scale, const u32x4r* __restrict__ resid,
+                                                        u32x4r* __restrict__ out, long S, long K, int vec_per_row) {
+  const long t = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  const long k = t / vec_per_row;
+  const int v = static_cast<int>(t - k * vec_per_row);
+  if (k >= K) return;
+  const long b = blockIdx.y;
+  const int s = index[k];
+  const long at = (b * K + k) * vec_per_row + v;
+  u32x4r x{0u, 0u, 0u, 0u};
+  if (s >= 0) x = src[(b * S + s) * vec_per_row + v];
+  const float f = scale != nullptr ? scale[b] : 1.f;
+  if (resid == nullptr && scale == nullptr) { out[at] = x; return; }
+  u32x4r r{0u, 0u, 0u, 0u};
+  if (resid != nullptr) r = resid[at];
+  u32x4r o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = __builtin_fmaf(__uint_as_float(x[e] << 16), f, __uint_as_float(r[e] << 16));
+    const float hi = __builtin_fmaf(__uint_as_float(x[e] & 0xffff0000u), f, __uint_as_float(r[e] & 0xffff0000u));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    o[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+  }
+  out[at] = o;
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void rows_pull_sum(const u32x4r* __restrict__ g, const int* __restrict__ inv_ptr,
                                                      const int* __restrict__ inv_idx, u32x4r* __restrict__ out,
@@ -201,6 +232,18 @@ extern "C" int transoar_rows_gather(const void* src, const int* index, void* out
   const dim3 grid(static_cast<unsigned>((K * vpr + 255) / 256), static_cast<unsigned>(B));
   hipLaunchKernelGGL(rows_gather, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                      static_cast<const u32x4r*>(src), index, static_cast<u32x4r*>(out), S, K, vpr);
+  return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_rows_gather_axpy(const void* src, const int* index, const float* scale, const void* resid, void* out,
+                                         int B, long S, long K, int row_bytes, void* hip_stream) {
+  if (!src || !index || !out) return -1;
+  if (B <= 0 || S <= 0 || K <= 0 || row_bytes <= 0 || (row_bytes & 15)) return -2;
+  const int vpr = row_bytes / 16;
+  const dim3 grid(static_cast<unsigned>((K * vpr + 255) / 256), static_cast<unsigned>(B));
+  hipLaunchKernelGGL(rows_gather_axpy, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<const u32x4r*>(src), index, scale, static_cast<const u32x4r*>(resid),
+                     static_cast<u32x4r*>(out), S, K, vpr);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -13,6 +13,8 @@ lib = ctypes.CDLL(_LIB_PATH)
 _i, _p, _l = ctypes.c_int, ctypes.c_void_p, ctypes.c_long
 lib.transoar_rows_gather.restype = _i
 lib.transoar_rows_gather.argtypes = [_p, _p, _p, _i, _l, _l, _i, _p]
+lib.transoar_rows_gather_axpy.restype = _i
+lib.transoar_rows_gather_axpy.argtypes = [_p, _p, _p, _p, _p, _i, _l, _l, _i, _p]
 lib.transoar_rows_pull_sum.restype = _i
 lib.transoar_rows_pull_sum.argtypes = [_p, _p, _p, _p, _i, _l, _l, _i, _i, _p]
 lib.transoar_rows_colsum.restype = _i
@@ -95,6 +97,29 @@ def gather(x, index):
                                       c * x.element_size(), torch.cuda.current_stream().cuda_stream)
     if rc:
         raise RuntimeError("transoar_rows_gather failed with code %d" % rc)
+    return out
+
+
+def gather_axpy(x, index, scale=None, resid=None):
+    """bf16 x (B,S,C) row-dense, index int32 (K,), scale (B,) fp32 or None, resid (B,K,C) contiguous bf16 or None
+    -> resid + scale[b] * x[:, index] (B,K,C) in one pass (negative index: a zero row)."""
+    if x.dtype != torch.bfloat16 or (resid is not None and (resid.dtype != torch.bfloat16 or not resid.is_contiguous())):
+        raise RuntimeError("gather_axpy: bf16 rows, contiguous residual")
+    if not row_dense(x):
+        x = x.contiguous()
+    b, s, c = x.shape
+    if b > 1:
+        s = x.stride(0) // c
+    k = index.numel()
+    if resid is not None and tuple(resid.shape) != (b, k, c):
+        raise RuntimeError("gather_axpy: residual must be (B, K, C)")
+    out = torch.empty((b, k, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_rows_gather_axpy(x.data_ptr(), index.data_ptr(), None if scale is None else scale.data_ptr(),
+                                           None if resid is None else resid.data_ptr(), out.data_ptr(), b, s, k,
+                                           c * x.element_size(), torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise RuntimeError("transoar_rows_gather_axpy failed with code %d" % rc)
     return out
 
 
