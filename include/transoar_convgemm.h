@@ -78,6 +78,16 @@ int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw,
                           unsigned taps_d, unsigned taps_h, unsigned taps_w, int chunks, int taps_out, void* hip_stream);
 
 /*
+ * A token linear layer's weight AND bias gradient in one pass over dy (reference: the autograd of the nn.Linear layers of
+ * backbones/encoder_blocks.py -- qkv, proj, fc1, fc2 of every Swin block): dw (Cout, Cin) = dy^T x as above (one tap), and
+ * db (Cout) = sum_t dy[t][:] from the same MFMAs, as the product's column Cin against a column of ones that stands in the x
+ * tile's padding.  dy (T, Cout), x (T, Cin) bf16; part as above (taps_out = 1); bias_part: chunks * Cout floats of scratch.
+ * Cin must not be a multiple of the channel tile (64 when Cin, Cout <= 64, else 128): TRANSOAR_CONVGEMM_ERR_DIM otherwise.
+ */
+int transoar_linear_wgrad_bias(const void* dy, const void* x, float* part, float* dw, float* bias_part, float* db, int T, int Cin,
+                               int Cout, int chunks, void* hip_stream);
+
+/*
  * The same weight gradient (all 27 taps, taps_out = 27, forward tap lists) for layers with Cin, Cout <= 64, more than 32
  * channels on at least one side and MW % 64 == 0 (the 24 -> 48 / stride 2 and 48 -> 48 layers of stage 1): a workgroup
  * owns one filter plane kd and keeps the three x rows of its plane in an LDS ring, so that x and dy are fetched 3 times

@@ -109,12 +109,15 @@ int transoar_sampling_head_backward(const float* g_loc, const float* g_attn, con
  *   forward:  y16 (rows, cols) bf16 = LayerNorm(x) * weight + bias, x bf16 or fp32; mean / rstd (rows) fp32 are kept for
  *             the backward
  *   backward: dx (x's type) from g16 (bf16); partials (transoar_ln_rows_partial_rows(), 2 * cols) fp32: every row holds a
- *             partial sum of [weight gradient | bias gradient] (column-sum them, e.g. transoar_rows_colsum_small)
+ *             partial sum of [weight gradient | bias gradient] (column-sum them, e.g. transoar_rows_colsum_small).
+ *             dx_add (x's type and shape) or NULL: a gradient that reaches x past the norm (the block's shortcut), added to dx
+ *             in the same pass.
  */
 int transoar_ln_rows_forward(const void* x, int x_is_bf16, const float* weight, const float* bias, float eps, void* y16,
                              float* mean, float* rstd, long rows, int cols, void* hip_stream);
 int transoar_ln_rows_backward(const void* g16, const void* x, int x_is_bf16, const float* weight, const float* mean,
-                              const float* rstd, void* dx, float* partials, long rows, int cols, void* hip_stream);
+                              const float* rstd, const void* dx_add, void* dx, float* partials, long rows, int cols,
+                              void* hip_stream);
 int transoar_ln_rows_partial_rows(void);
 
 int transoar_tokens_abi_version(void);

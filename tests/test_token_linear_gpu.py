@@ -151,3 +151,20 @@ def test_gelu_mlp_matches_the_unfused_chain(tokens, c, hidden):
         assert (a - b).abs().max().item() <= tol * a.abs().max().item(), name
     frac = (res[0][0] != res[1][0]).float().mean().item()
     assert frac <= 0.05, frac          # ... and nearly all outputs are bit-identical
+
+
+@pytest.mark.parametrize("tokens,k,n", [(20037, 48, 144), (9001, 48, 48), (30000, 192, 48), (12345, 96, 384), (8192, 192, 768)])
+def test_linear_wgrad_with_the_bias_gradient_in_its_padding_column(tokens, k, n):
+    """conv_gemm.linear_wgrad_bias (transoar_linear_wgrad_bias): dW = gy^T x and db = sum_t gy from ONE pass over gy -- a column
+    of ones in the x tile's padding makes the bias gradient column K of the product -- against fp64 of the same bf16 operands,
+    and dW bit-identical to the kernel without the ones column."""
+    from transoar_amd import conv_gemm
+    g = torch.Generator().manual_seed(tokens)
+    x = torch.randn(tokens, k, generator=g).to(torch.bfloat16).cuda()
+    gy = (torch.randn(tokens, n, generator=g) + 0.25).to(torch.bfloat16).cuda()
+    assert conv_gemm.linear_wgrad_bias_usable(k, n)
+    dw, db = conv_gemm.linear_wgrad_bias(x, gy)
+    assert torch.equal(dw, conv_gemm.linear_wgrad(x, gy))
+    tw, tb = gy.double().t() @ x.double(), gy.double().sum(0)
+    assert (dw.double() - tw).abs().max().item() <= 1e-5 * tw.abs().max().item()
+    assert (db.double() - tb).abs().max().item() <= 1e-5 * tb.abs().max().item()

@@ -270,3 +270,42 @@ def test_layernorm_rows_matches_torch(cols, xdt):
     assert y.dtype == torch.bfloat16 and rel(y, yr) <= 2.0 ** -8
     assert x.grad.dtype == xdt and rel(x.grad, xr.grad) <= (2.0 ** -7 if xdt == torch.bfloat16 else 1e-4)
     assert rel(norm.weight.grad, wr.grad) <= 1e-3 and rel(norm.bias.grad, br.grad) <= 1e-3
+
+
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float32])
+def test_layernorm_rows_fork_sums_the_shortcut_gradient_in_its_backward(xdt):
+    """(x, LayerNorm(x)) as one node (tokens.layernorm_rows_fork, the Swin block's pre-norm shortcut): the same values, and the
+    input gradient = shortcut gradient + the norm's, summed inside the backward kernel (fp32, one rounding) instead of by an
+    accumulation pass; a missing shortcut / branch gradient is handled."""
+    from transoar_amd import tokens
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n_rows, cols = 50003, 96
+    x0 = (torch.randn(n_rows, cols, device="cuda", generator=g) * 2 + 0.5).to(xdt)
+    norm = torch.nn.LayerNorm(cols).cuda()
+    gy = torch.randn(n_rows, cols, device="cuda", generator=g).to(torch.bfloat16)
+    gs = torch.randn(n_rows, cols, device="cuda", generator=g).to(xdt)
+    x = x0.clone().requires_grad_()
+    xs, y = tokens.layernorm_rows_fork(x, norm)
+    assert torch.equal(xs, x0) and xs.data_ptr() == x.data_ptr()
+    torch.autograd.backward((xs, y), (gs, gy))
+    fused, gw, gb = x.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()
+    x = x0.clone().requires_grad_()
+    norm.zero_grad()
+    y2 = tokens.layernorm_rows(x, norm)
+    assert torch.equal(y, y2)
+    y2.backward(gy)
+    want = x.grad.float() + gs.float()
+    tol = 2.0 ** -7 if xdt == torch.bfloat16 else 1e-6
+    assert (fused.float() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert torch.equal(gw, norm.weight.grad) and torch.equal(gb, norm.bias.grad)
+    # only the shortcut is used / only the branch is used
+    x = x0.clone().requires_grad_()
+    xs, y = tokens.layernorm_rows_fork(x, norm)
+    xs.backward(gs)
+    assert torch.equal(x.grad, gs)
+    x = x0.clone().requires_grad_()
+    xs, y = tokens.layernorm_rows_fork(x, norm)
+    y.backward(gy)
+    x2 = x0.clone().requires_grad_()
+    tokens.layernorm_rows(x2, norm).backward(gy)
+    assert torch.equal(x.grad, x2.grad)

@@ -28,6 +28,8 @@ def _load():
     lib.transoar_conv3d_finish.argtypes = [p, p, p, ctypes.c_long, i, i, p]
     lib.transoar_conv3d_wgrad.restype = i
     lib.transoar_conv3d_wgrad.argtypes = [p, p, p, p] + [i] * 10 + [u] * 3 + [i, i, p]
+    lib.transoar_linear_wgrad_bias.restype = i
+    lib.transoar_linear_wgrad_bias.argtypes = [p] * 6 + [i] * 4 + [p]
     lib.transoar_conv3d_wgrad_ring.restype = i
     lib.transoar_conv3d_wgrad_ring.argtypes = [p, p, p, p] + [i] * 11 + [p]
     lib.transoar_conv3d_wgrad_part_floats.restype = ctypes.c_long
@@ -291,6 +293,29 @@ def linear_wgrad(x, gy):
     t, k = x.shape
     nn_ = gy.shape[1]
     return _wgrad(x, gy, (1, 1, 1, t, k, nn_, 1, 1, t, 1), (TAPS_ONE,) * 3, 1, (nn_, k))
+
+
+def linear_wgrad_bias_usable(k, n):
+    """Does the last K tile have a padding column for the ones that sum gy (transoar_linear_wgrad_bias)?"""
+    return k % (64 if (k <= 64 and n <= 64) else 128) != 0
+
+
+def linear_wgrad_bias(x, gy):
+    """x (T, K), gy (T, N) bf16 contiguous -> (dW (N, K), db (N,)) fp32 = (gy^T x, gy.sum(0)) in one pass over gy."""
+    t, k = x.shape
+    nn_ = gy.shape[1]
+    bt = 64 if (k <= 64 and nn_ <= 64) else 128
+    tiles = ((nn_ + bt - 1) // bt) * ((k + bt - 1) // bt)
+    budget = WGRAD_BLOCKS * (2 if (t >= (1 << 20) or tiles >= 64) else 1)
+    chunks = max(1, min(budget // tiles, t // 1024 if t >= 1024 else 1))
+    part = torch.empty(lib.transoar_conv3d_wgrad_part_floats(k, nn_, chunks, 1), dtype=torch.float32, device=x.device)
+    bias_part = torch.empty(chunks * nn_, dtype=torch.float32, device=x.device)
+    dw = torch.empty((nn_, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(nn_, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.transoar_linear_wgrad_bias(gy.data_ptr(), x.data_ptr(), part.data_ptr(), dw.data_ptr(), bias_part.data_ptr(), db.data_ptr(),
+                                              t, k, nn_, chunks, _stream()), "transoar_linear_wgrad_bias")
+    return dw, db
 
 
 def supported(cin, cout, rows):

@@ -390,7 +390,7 @@ template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
     const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X, float* __restrict__ part, ConvGeom g,
     unsigned tp_d, unsigned tp_h, unsigned tp_w, int chunks, int rows_per_chunk, int tiles_co, int tiles_ci, int slabs,
-    unsigned dy_bytes, unsigned x_bytes) {
+    unsigned dy_bytes, unsigned x_bytes, float* __restrict__ bias_part) {
   constexpr int BT = 64 * TW;                // block tile side (channels)
   constexpr int WP = 2 * BT;                 // bytes per staged row: BT channels, no padding -- the 64-byte windows the transposing reads
                                              // take out of 4 consecutive rows are XOR-swizzled over the banks instead (row_swz)
@@ -436,6 +436,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
   const bool co_ok = co0 + l_piece * 8 < g.Cout, ci_ok = ci0 + l_piece * 8 < g.Cin;
   const unsigned y_col = co_ok ? static_cast<unsigned>(co0 + l_piece * 8) * 2u : 0x80000000u;
   const unsigned x_col = ci_ok ? static_cast<unsigned>(ci0 + l_piece * 8) * 2u : 0x80000000u;
+  // bias_part (a linear layer's weight gradient, Cin not a multiple of the tile): the column sums of dY -- the layer's bias
+  // gradient -- come out of the same MFMAs as column Cin of the product, against a column of ONES standing in the X tile's
+  // first padding piece.  That piece is written once here and left out of the DMA (its lanes are masked off); rows past
+  // the chunk read dY = 0 and add nothing.  (A separate column-sum kernel re-read dY: 0.7 ms per Swin step.)
+  const bool bias_here = bias_part != nullptr && tci == tiles_ci - 1;
+  const bool ones_piece = bias_here && ci0 + l_piece * 8 == g.Cin;
+  if (ones_piece) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int i = 0; i < WK * PR / 256; ++i)
+        *reinterpret_cast<u32x4*>(&lds[st][WK * WP + (s_row + (256 / PR) * i) * WP + s_piece * 16]) = u32x4{0x00003f80u, 0u, 0u, 0u};
+  }
   // The source row of every voxel row of a segment is worked out ONCE per workgroup into LDS (byte offset of the shifted x
   // voxel's first channel, or an out-of-range marker for the padding): with the decomposition m -> (nb, md, mh, mw) done
   // per K step and thread, the kernel issued 12.7 VALU instructions per MFMA and was VALU-bound (profiles/r03_conv_pmc.txt).
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
       const unsigned xo = in ? xrow[m - seg0] : 0x80000000u;
       // (a marker plus the column offset stays out of range: the buffers are < 2^31 bytes)
       dma16(rdy, in ? static_cast<unsigned>(m) * static_cast<unsigned>(g.Cout) * 2u + y_col : 0x80000000u, base + i * (RS * WP));
-      dma16(rx, xo + x_col, base + WK * WP + i * (RS * WP));
+      if (!ones_piece) dma16(rx, xo + x_col, base + WK * WP + i * (RS * WP));
     }
   };
   f32x16 acc[TW][TW];          // [co tile][ci tile] of the wave's quadrant
@@ -532,6 +545,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(
 #pragma unroll
     for (int b = 0; b < TW; ++b) {
       const int ci = ci0 + wn * 32 * TW + b * 32 + (lane & 31);
+      if (bias_here && ci == g.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wm * 32 * TW + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          if (co < g.Cout) bias_part[static_cast<long>(chunk) * g.Cout + co] = acc[a][b][r];
+        }
+      }
       if (ci >= g.Cin) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -552,6 +572,47 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
   __shared__ __attribute__((aligned(16))) float sh[kReducePairs * 27];
   const long e0 = static_cast<long>(blockIdx.x) * kReducePairs;
   const int quads = kReducePairs / 4;
+  const int work = quads * slabs;                    // float4 columns of this block: 32 for a linear layer, 864 for 27 taps
+  if (work < 256) {
+    // a linear layer's gradient (slabs == 1): 32 columns -- with one thread per column, 7 of 8 threads idled while the other
+    // walked up to 1024 chunks one dependent load after the other (24 us per launch, 57 launches per Swin step).  The
+    // chunks are dealt to 256 / work thread groups instead; LDS adds their sums.
+    const int P = 256 / work;
+    const int sub = threadIdx.x / work, idx = threadIdx.x - sub * work;
+    const int tap = idx / quads, q = idx - tap * quads;
+    float4 v{0.f, 0.f, 0.f, 0.f};
+    if (sub < P && e0 + 4 * q < coci) {
+      const float* src = part + static_cast<long>(tap) * coci + e0 + 4 * q;
+      const long step = static_cast<long>(slabs) * coci;
+      int k = sub;
+      for (; k + 3 * P < chunks; k += 4 * P) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (k + 0 * P) * step), b = *reinterpret_cast<const float4*>(src + (k + 1 * P) * step);
+        const float4 c = *reinterpret_cast<const float4*>(src + (k + 2 * P) * step), d = *reinterpret_cast<const float4*>(src + (k + 3 * P) * step);
+        v.x += (a.x + b.x) + (c.x + d.x); v.y += (a.y + b.y) + (c.y + d.y);
+        v.z += (a.z + b.z) + (c.z + d.z); v.w += (a.w + b.w) + (c.w + d.w);
+      }
+      for (; k < chunks; k += P) {
+        const float4 a = *reinterpret_cast<const float4*>(src + k * step);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+    }
+    float4* turn = reinterpret_cast<float4*>(sh);                  // [group][column]: 256 float4 at most
+    if (sub < P) turn[sub * work + idx] = v;
+    __syncthreads();
+    if (sub == 0) {
+      for (int g2 = 1; g2 < P; ++g2) {
+        const float4 o = turn[g2 * work + idx];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+    }
+    __syncthreads();
+    if (sub == 0) {
+      sh[(4 * q + 0) * slabs + tap] = v.x;
+      sh[(4 * q + 1) * slabs + tap] = v.y;
+      sh[(4 * q + 2) * slabs + tap] = v.z;
+      sh[(4 * q + 3) * slabs + tap] = v.w;
+    }
+  } else {
   for (int idx = threadIdx.x; idx < quads * slabs; idx += 256) {
     const int tap = idx / quads, q = idx - tap * quads;
     float4 v{0.f, 0.f, 0.f, 0.f};
@@ -574,6 +635,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
     sh[(4 * q + 1) * slabs + tap] = v.y;
     sh[(4 * q + 2) * slabs + tap] = v.z;
     sh[(4 * q + 3) * slabs + tap] = v.w;
+  }
   }
   __syncthreads();
   const long total = coci * slabs, base = e0 * slabs;             // both multiples of 4
@@ -765,9 +827,9 @@ extern "C" int transoar_conv3d_finish(const float* y32, const float* bias, void*
 
 extern "C" long transoar_conv3d_wgrad_part_floats(int Cin, int Cout, int chunks, int taps_out) { return static_cast<long>(taps_out) * Cin * Cout * chunks; }
 
-extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
-                                     int Cout, int MD, int MH, int MW, int src_stride, unsigned taps_d, unsigned taps_h,
-                                     unsigned taps_w, int chunks, int taps_out, void* hip_stream) {
+static int wgrad_launch(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
+                        int Cout, int MD, int MH, int MW, int src_stride, unsigned taps_d, unsigned taps_h,
+                        unsigned taps_w, int chunks, int taps_out, float* bias_part, float* db, void* hip_stream) {
   if (!dy || !x || !part || !dw) return TRANSOAR_CONVGEMM_ERR_NULL;
   const ConvGeom g{N, SD, SH, SW, MD, MH, MW, MD, MH, MW, src_stride, 1, 0, 0, 0, Cin, Cout};
   const int rc = check_geom(g);
@@ -791,13 +853,32 @@ extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part,
   const unsigned dyb = static_cast<unsigned>(M * Cout * 2), xb = static_cast<unsigned>(static_cast<long>(N) * SD * SH * SW * Cin * 2);
   if (small)
     hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
-                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb);
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb, bias_part);
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<const unsigned short*>(dy),
-                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb);
+                       static_cast<const unsigned short*>(x), part, g, taps_d, taps_h, taps_w, chunks, rows_per_chunk, tiles_co, tiles_ci, taps_out, dyb, xb, bias_part);
   const long coci = static_cast<long>(Cout) * Cin;
   hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((coci + kReducePairs - 1) / kReducePairs)), dim3(256), 0, st, part, dw, chunks, taps_out, coci);
+  if (bias_part != nullptr)          // the same reduction over the chunks for the (chunks, Cout) bias partials
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(static_cast<unsigned>((Cout + kReducePairs - 1) / kReducePairs)), dim3(256), 0, st, bias_part, db, chunks, 1,
+                       static_cast<long>(Cout));
   return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int transoar_conv3d_wgrad(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,
+                                     int Cout, int MD, int MH, int MW, int src_stride, unsigned taps_d, unsigned taps_h,
+                                     unsigned taps_w, int chunks, int taps_out, void* hip_stream) {
+  return wgrad_launch(dy, x, part, dw, N, SD, SH, SW, Cin, Cout, MD, MH, MW, src_stride, taps_d, taps_h, taps_w, chunks, taps_out, nullptr, nullptr,
+                      hip_stream);
+}
+
+extern "C" int transoar_linear_wgrad_bias(const void* dy, const void* x, float* part, float* dw, float* bias_part, float* db, int T,
+                                          int Cin, int Cout, int chunks, void* hip_stream) {
+  if (!bias_part || !db) return TRANSOAR_CONVGEMM_ERR_NULL;
+  const int bt = (Cin <= 64 && Cout <= 64) ? 64 : 128;
+  if (Cin % bt == 0) return TRANSOAR_CONVGEMM_ERR_DIM;            // no padding column in the last tile to carry the ones
+  constexpr unsigned kOneTap = 1u | (1u << 2) | (1u << 4);          // one tap: delta 0, slot 1 (conv_gemm.py TAPS_ONE)
+  return wgrad_launch(dy, x, part, dw, 1, 1, 1, T, Cin, Cout, 1, 1, T, 1, kOneTap, kOneTap, kOneTap, chunks, 1, bias_part, db, hip_stream);
 }
 
 extern "C" int transoar_conv3d_wgrad_ring(const void* dy, const void* x, float* part, float* dw, int N, int SD, int SH, int SW, int Cin,

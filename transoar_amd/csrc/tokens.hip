@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void ln_rows_fwd(const void* __restrict__ x, c
 
 template <int G, bool XBF>
 __global__ __launch_bounds__(256) void ln_rows_bwd(const uint4* __restrict__ g16, const void* __restrict__ x, const float* __restrict__ weight,
-                                                   const float* __restrict__ mean_in, const float* __restrict__ rstd_in, void* __restrict__ dx,
+                                                   const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                   const void* __restrict__ dx_add, void* __restrict__ dx,
                                                    float* __restrict__ partials, long rows, int cols) {
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -655,6 +656,12 @@ __global__ __launch_bounds__(256) void ln_rows_bwd(const uint4* __restrict__ g16
       float o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = rstd * (gw[i] - c1 - xh[i] * c2);
+      if (dx_add != nullptr) {                       // the gradient that reaches x past the norm (a residual branch): summed here
+        float a[8];
+        ln_load8<XBF>(dx_add, row, cols, c0, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += a[i];
+      }
       if (XBF) {
         reinterpret_cast<uint4*>(dx)[(row * cols + c0) >> 3] =
             uint4{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
@@ -875,14 +882,15 @@ extern "C" int transoar_ln_rows_forward(const void* x, int x_is_bf16, const floa
 extern "C" int transoar_ln_rows_partial_rows(void) { return kLnBlocks * 4; }
 
 extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_is_bf16, const float* weight, const float* mean,
-                                         const float* rstd, void* dx, float* partials, long rows, int cols, void* hip_stream) {
+                                         const float* rstd, const void* dx_add, void* dx, float* partials, long rows, int cols,
+                                         void* hip_stream) {
   if (!g16 || !x || !weight || !mean || !rstd || !dx || !partials) return TRANSOAR_TOK_ERR_NULL;
   if (rows <= 0 || cols < 8 || cols > 512 || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int g = std::max(8, ln_group(cols));
   LN_DISPATCH(g, {
-    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_bwd<G, true>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx, partials, rows, cols);
-    else hipLaunchKernelGGL((ln_rows_bwd<G, false>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx, partials, rows, cols);
+    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_bwd<G, true>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx_add, dx, partials, rows, cols);
+    else hipLaunchKernelGGL((ln_rows_bwd<G, false>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx_add, dx, partials, rows, cols);
   });
   return static_cast<int>(hipGetLastError());
 }
@@ -890,4 +898,4 @@ extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_i
 extern "C" int transoar_pos_query_partial_rows(void) { return kPersistentWaves / kWaves; }
 
 extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
-extern "C" int transoar_tokens_abi_version(void) { return 6; }
+extern "C" int transoar_tokens_abi_version(void) { return 7; }

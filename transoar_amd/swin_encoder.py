@@ -38,6 +38,14 @@ def _fast(x):
     return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
 
 
+def _norm16_fork(x, norm):
+    """(x for the shortcut, LayerNorm(x) in bf16): one autograd node where the short-row kernel applies, so that the shortcut's
+    gradient joins the norm's inside its backward kernel."""
+    if fused_tokens.layernorm_rows_usable(x, norm) and x.requires_grad:
+        return fused_tokens.layernorm_rows_fork(x, norm)
+    return x, _norm16(x, norm)
+
+
 def _norm16(x, norm):
     """LayerNorm rounded to bf16: the short-row kernel (tokens.layernorm_rows: 48 .. 512 channels) or torch + a cast."""
     if fused_tokens.layernorm_rows_usable(x, norm):
@@ -272,7 +280,7 @@ class SwinBlock(nn.Module):
         lay = window_layout(grid, win, shift, x.device)
         if _fast(x) and (c * 2) % 16 == 0:
             # bf16 tokens (what the qkv projection rounds them to anyway) through the row kernels both ways
-            y = _norm16(x, self.norm1)
+            x, y = _norm16_fork(x, self.norm1)
             y = _Rows.apply(y, lay.gather32, lay.gather_back).view(b, lay.n_windows, lay.n_per, c)           # pad (zero rows) + shift + partition
             y = self.attn(y, lay.mask, lay.mask_bits)
             factor = self.drop_path.factor(x) if isinstance(self.drop_path, DropPath) else None
@@ -282,7 +290,8 @@ class SwinBlock(nn.Module):
             else:
                 y = _Rows.apply(y.reshape(b, -1, c).contiguous(), lay.scatter32, lay.scatter_back)            # merge + shift back + crop
                 x = x + y if factor is None else torch.addcmul(x, y, factor)
-            return _add_path(x, self.mlp(_norm16(x, self.norm2)), self.drop_path)
+            x, y = _norm16_fork(x, self.norm2)
+            return _add_path(x, self.mlp(y), self.drop_path)
         y = self.norm1(x)
         y = torch.cat((y, y.new_zeros(b, 1, c)), dim=1)                      # row n_tok: the padding token
         y = y[:, lay.gather].view(b, lay.n_windows, lay.n_per, c)           # pad + shift + partition

@@ -85,6 +85,12 @@ def weight_bias_grad(gy, x, want_w, want_b):
     weight gradient above and rows.colsum_any."""
     if want_w and want_b and USE_HIP_WGRAD and gemm.wgrad384_usable(gy, x):
         return gemm.wgrad384(gy, x, with_bias=True)
+    t, n = gy.shape
+    k = x.shape[1]
+    if (want_w and want_b and USE_HIP_WGRAD and gy.is_cuda and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+            and gy.is_contiguous() and x.is_contiguous() and n % 8 == 0 and k % 8 == 0 and t < (1 << 21)
+            and not gemm.wgrad384_usable(gy, x) and conv_gemm.linear_wgrad_bias_usable(k, n)):
+        return conv_gemm.linear_wgrad_bias(x, gy)       # the Swin widths: the column sums ride in the product's padding column
     return (weight_grad(gy, x) if want_w else None), (rows.colsum_any(gy) if want_b else None)
 
 

@@ -45,10 +45,10 @@ def _load():
     lib.transoar_ln_rows_forward.restype = i
     lib.transoar_ln_rows_forward.argtypes = [p, i, p, p, ctypes.c_float, p, p, p, lg, i, p]
     lib.transoar_ln_rows_backward.restype = i
-    lib.transoar_ln_rows_backward.argtypes = [p, p, i, p, p, p, p, p, lg, i, p]
+    lib.transoar_ln_rows_backward.argtypes = [p, p, i, p, p, p, p, p, p, lg, i, p]
     lib.transoar_ln_rows_partial_rows.restype = i
     lib.transoar_tokens_abi_version.restype = i
-    if lib.transoar_tokens_abi_version() != 6:
+    if lib.transoar_tokens_abi_version() != 7:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -338,6 +338,41 @@ def sampling_head(proj, reference_points, shapes, m, lv, pt):
     return _SamplingHead.apply(proj, reference_points, shapes, m, lv, pt)
 
 
+def _ln_rows_forward(x, weight, bias, eps):
+    cols = x.shape[-1]
+    n_rows = x.numel() // cols
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(n_rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n_rows, dtype=torch.float32, device=x.device)
+    w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_ln_rows_forward(x.data_ptr(), int(x.dtype == torch.bfloat16), w32.data_ptr(), b32.data_ptr(), float(eps),
+                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n_rows, cols,
+                                          torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_ln_rows_forward failed with code %d" % rc)
+    return y, w32, mean, rstd
+
+
+def _ln_rows_backward(g, x, w32, mean, rstd, g_add=None):
+    cols = x.shape[-1]
+    n_rows = x.numel() // cols
+    g = g.to(torch.bfloat16).contiguous()
+    if g_add is not None:
+        g_add = g_add.to(x.dtype).contiguous()
+    dx = torch.empty_like(x)
+    partials = torch.empty((lib.transoar_ln_rows_partial_rows(), 2 * cols), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.transoar_ln_rows_backward(g.data_ptr(), x.data_ptr(), int(x.dtype == torch.bfloat16), w32.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), _ptr(g_add), dx.data_ptr(), partials.data_ptr(), n_rows, cols,
+                                           torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("transoar_ln_rows_backward failed with code %d" % rc)
+    from . import rows
+    sums = rows.colsum_any(partials)
+    return dx, sums[:cols], sums[cols:]
+
+
 class _LayerNormRows(torch.autograd.Function):
     """nn.LayerNorm over the last axis of a (…, cols) tensor with 8 <= cols <= 512, cols % 8 == 0 (the Swin stages'
     norms, encoder_blocks.py:143-327), output bf16: one kernel each way (include/transoar_tokens.h: transoar_ln_rows_*)."""
@@ -345,38 +380,35 @@ class _LayerNormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
         x = x.contiguous()
-        cols = x.shape[-1]
-        n_rows = x.numel() // cols
-        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-        mean = torch.empty(n_rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(n_rows, dtype=torch.float32, device=x.device)
-        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        with torch.cuda.device(x.device):
-            rc = lib.transoar_ln_rows_forward(x.data_ptr(), int(x.dtype == torch.bfloat16), w32.data_ptr(), b32.data_ptr(), float(eps),
-                                              y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n_rows, cols,
-                                              torch.cuda.current_stream().cuda_stream)
-        if rc != 0:
-            raise RuntimeError("transoar_ln_rows_forward failed with code %d" % rc)
+        y, w32, mean, rstd = _ln_rows_forward(x, weight, bias, eps)
         ctx.save_for_backward(x, w32, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        dx, gw, gb = _ln_rows_backward(g, *ctx.saved_tensors)
+        return dx, gw, gb, None
+
+
+class _LayerNormRowsFork(torch.autograd.Function):
+    """(x, LayerNorm(x)) of a pre-norm residual block as ONE node: the gradient arriving at x past the norm (the shortcut) is
+    added to the norm's input gradient inside the backward kernel instead of by autograd's accumulation pass over the tokens."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        y, w32, mean, rstd = _ln_rows_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, w32, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_x, g_y):
         x, w32, mean, rstd = ctx.saved_tensors
-        cols = x.shape[-1]
-        n_rows = x.numel() // cols
-        g = g.to(torch.bfloat16).contiguous()
-        dx = torch.empty_like(x)
-        partials = torch.empty((lib.transoar_ln_rows_partial_rows(), 2 * cols), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            rc = lib.transoar_ln_rows_backward(g.data_ptr(), x.data_ptr(), int(x.dtype == torch.bfloat16), w32.data_ptr(), mean.data_ptr(),
-                                               rstd.data_ptr(), dx.data_ptr(), partials.data_ptr(), n_rows, cols,
-                                               torch.cuda.current_stream().cuda_stream)
-        if rc != 0:
-            raise RuntimeError("transoar_ln_rows_backward failed with code %d" % rc)
-        from . import rows
-        sums = rows.colsum_any(partials)
-        return dx, sums[:cols], sums[cols:], None
+        if g_y is None:
+            return g_x, None, None, None
+        dx, gw, gb = _ln_rows_backward(g_y, x, w32, mean, rstd, g_x)
+        return dx, gw, gb, None
 
 
 def layernorm_rows_usable(x, norm):
@@ -384,6 +416,11 @@ def layernorm_rows_usable(x, norm):
     return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and 8 <= cols <= 512 and cols % 8 == 0
             and tuple(norm.normalized_shape) == (cols,) and norm.elementwise_affine and norm.bias is not None
             and x.data_ptr() % 16 == 0)
+
+
+def layernorm_rows_fork(x, norm):
+    """-> (x, norm(x) rounded to bf16); use the returned x for the block's shortcut (see _LayerNormRowsFork)."""
+    return _LayerNormRowsFork.apply(x, norm.weight, norm.bias, norm.eps)
 
 
 def layernorm_rows(x, norm):
