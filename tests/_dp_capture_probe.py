@@ -83,6 +83,7 @@ def main():
             rel.append((float((p.detach().double() - q.detach().double()).norm()) / den, n))
     rel.sort(reverse=True)
     out["update_rel_worst"], out["update_rel_median"] = rel[0], rel[len(rel) // 2][0]
+    out["update_rel_p90"] = rel[len(rel) // 10][0]
     out["loss_finite"] = bool(torch.isfinite(cap._static_total))
     print(json.dumps(out), flush=True)
     dist.destroy_process_group()

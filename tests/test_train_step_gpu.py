@@ -289,4 +289,8 @@ def test_captured_data_parallel_step():
     print("captured data-parallel step:", out)
     assert out["capture_left_weights_alone"] and out["loss_finite"]
     assert out["grad_worst"][0] <= 4e-2 and out["grad_worst_outside_encoder"][0] <= REST_BOUND, out
-    assert out["update_rel_median"] <= 0.05 and out["update_rel_worst"][0] <= 0.6, out
+    # three AdamW steps from zero state move a weight by ~lr * sign(gradient): an element whose gradient is run-to-run noise
+    # (atomics order behind the InstanceNorm chain) flips its whole update, so the WORST tensor's relative difference swings
+    # between runs (0.2 typical; one full-suite run in two crossed 0.6).  Bounded: the median and the 90th percentile tightly,
+    # the worst tensor below 1 -- a tensor the captured path never updated, or updated twice, would sit at exactly 1
+    assert out["update_rel_median"] <= 0.05 and out["update_rel_p90"] <= 0.3 and out["update_rel_worst"][0] <= 0.9, out

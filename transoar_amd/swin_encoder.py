@@ -301,6 +301,29 @@ class SwinBlock(nn.Module):
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
 
+_MERGE_LISTS = {}
+
+
+def _merge_lists(grid, device):
+    """Row lists of PatchMerging's 2x2x2 regrouping on a (D, H, W) token grid: slot (D', H', W', block) <- source token (or -1:
+    the zero padding of an odd H / W), blocks in the reference's order (dd, dw, dh); and the inverse, slot of every source
+    token (-1: the last plane of an odd D, which the reference's stride-2 slicing drops)."""
+    key = (tuple(grid), str(device))
+    hit = _MERGE_LISTS.get(key)
+    if hit is None:
+        D, H, W = grid
+        d2, h2, w2 = D // 2, (H + 1) // 2, (W + 1) // 2
+        od, oh, ow, dd, dw, dh = torch.meshgrid(torch.arange(d2), torch.arange(h2), torch.arange(w2), torch.arange(2), torch.arange(2),
+                                                torch.arange(2), indexing="ij")
+        sd, sh, sw = 2 * od + dd, 2 * oh + dh, 2 * ow + dw
+        src = torch.where((sh < H) & (sw < W), (sd * H + sh) * W + sw, torch.full_like(sd, -1)).reshape(-1)
+        back = torch.full((D * H * W,), -1, dtype=torch.long)
+        ok = src >= 0
+        back[src[ok]] = torch.arange(src.numel())[ok]
+        hit = _MERGE_LISTS[key] = (src.int().to(device), back.int().to(device), (d2, h2, w2))
+    return hit
+
+
 class PatchMerging(nn.Module):
     """2x2x2 neighbours -> 8C channels -> LayerNorm -> Linear(8C, 2C, no bias) (encoder_blocks.py:298-327).
     Channel blocks in the reference's order: for d-offset 0,1: (h0,w0), (h1,w0), (h0,w1), (h1,w1).  Odd H/W are
@@ -314,6 +337,11 @@ class PatchMerging(nn.Module):
 
     def forward(self, x):
         b, d, h, w, c = x.shape
+        if _fast(x) and x.dtype == torch.bfloat16 and x.is_contiguous() and (c * 2) % 16 == 0 and d >= 2:
+            # the 2x2x2 regrouping (pad, slice, permute, reshape: a strided copy each way) as the row gather of the window layout
+            src, back, (d2, h2, w2) = _merge_lists((d, h, w), x.device)
+            y = _Rows.apply(x.view(b, d * h * w, c), src, back).view(b, d2, h2, w2, 8 * c)
+            return token_linear(_norm16(y, self.norm), self.reduction.weight, None, force_hip=True, min_tokens=MIN_TOKENS)
         if h % 2 or w % 2:
             x = F.pad(x, (0, 0, 0, w % 2, 0, h % 2))
             h, w = h + h % 2, w + w % 2
