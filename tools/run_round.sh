@@ -28,5 +28,8 @@ TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --no-graph --steps 20 --wa
 TRANSOAR_FORCE_DP=1 python bench.py --no-cpu-baseline --graph --steps 20 --warmup 5 > $O/${T}_bench_one_rank_rccl_graph.json 2>/dev/null; one $O/${T}_bench_one_rank_rccl_graph.json
 python bench.py --swin --no-refine --no-cpu-baseline > $O/${T}_bench_swin.json 2> /dev/null; one $O/${T}_bench_swin.json
 python bench.py --swin --no-cpu-baseline > $O/${T}_bench_swin_refine.json 2> /dev/null; one $O/${T}_bench_swin_refine.json
+bash tools/profile_step.sh ${T}_swin --swin --no-refine > /dev/null 2>&1; cp $O/${T}_swin_bench_eager_by_family.txt $O/${T}_bench_swin_by_family.txt; head -12 $O/${T}_bench_swin_by_family.txt
 python tools/bench_roi_attn.py > $O/${T}_roi_attn_bench.jsonl 2>/dev/null; tail -3 $O/${T}_roi_attn_bench.jsonl | cut -c1-220
-python bench.py --cpu-baseline-only --cpu-baseline-step > $O/${T}_cpu_step.json 2>/dev/null; tail -1 $O/${T}_cpu_step.json | cut -c1-300
+(python tools/bench_win_attn.py; python tools/bench_win_attn.py --shifted) > $O/${T}_win_attn_bench.jsonl 2>/dev/null; head -2 $O/${T}_win_attn_bench.jsonl | cut -c1-220
+python tools/bench_gelu_mlp.py > $O/${T}_gelu_mlp_bench.jsonl 2>/dev/null; head -1 $O/${T}_gelu_mlp_bench.jsonl | cut -c1-300
+[ -n "${SKIP_CPU_STEP:-}" ] || { python bench.py --cpu-baseline-only --cpu-baseline-step > $O/${T}_cpu_step.json 2>/dev/null; tail -1 $O/${T}_cpu_step.json | cut -c1-300; }

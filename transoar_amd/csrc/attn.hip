@@ -542,7 +542,7 @@ template <int HD> struct WinTile {
   // works on this one
   struct Regs { u32x4 a, b; };
   static __device__ __forceinline__ Regs fetch(const unsigned short* __restrict__ src, long tok_elems, int n) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int row = (threadIdx.x & 255) >> 1, half = threadIdx.x & 1;          // (a 512-thread workgroup: each half stages its own tiles)
     Regs r{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     if (row < n) {
       if constexpr (HD == 32) {
@@ -556,7 +556,7 @@ template <int HD> struct WinTile {
     return r;
   }
   static __device__ __forceinline__ void put(unsigned char* tile, const Regs& r) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int row = (threadIdx.x & 255) >> 1, half = threadIdx.x & 1;
     if constexpr (HD == 32) {
       *reinterpret_cast<u32x4*>(tile + off(row, 2 * half)) = r.a;
       *reinterpret_cast<u32x4*>(tile + off(row, 2 * half + 1)) = r.b;
@@ -913,6 +913,208 @@ __global__ __launch_bounds__(256) void win_attn_bwd(
   }
 }
 
+// The same backward with EIGHT waves per workgroup (round 5): two waves per SIMD of the one workgroup a CU holds, so that one
+// wave's exponentials run under the other's MFMAs and LDS round trips.  The row side splits the keys (wave = row tile x key
+// half: two of the four 32-key tiles each -- half the bias-gradient and bias registers), the key side splits the rows
+// (wave = key tile x row half); the half-sums of dq and of (dv, dk) meet through LDS across the barrier that follows them
+// anyway.  Staging: threads 0..255 fetch / put q and k, threads 256..511 v and dout.
+template <int HD>
+__global__ __launch_bounds__(512) void win_attn_bwd8(
+    const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ out, const unsigned short* __restrict__ dout,
+    const float* __restrict__ lse2, const float* __restrict__ bias, const unsigned* __restrict__ maskbits,
+    unsigned short* __restrict__ dqkv, float* __restrict__ dbias, int n, int heads, int n_win, int windows, float scale) {
+  using T = WinTile<HD>;
+  constexpr int kXq = 4 * 64 * 16 * 4, kXkv = 4 * 64 * 32 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * T::kBytes + 2 * kWinN * kWinPPitch + kXq + kXkv];
+  unsigned char* kt = lds;
+  unsigned char* vt = lds + T::kBytes;
+  unsigned char* qt = lds + 2 * T::kBytes;
+  unsigned char* dt = lds + 3 * T::kBytes;
+  unsigned char* pt = lds + 4 * T::kBytes;                      // P   [row][key] bf16
+  unsigned char* st = pt + kWinN * kWinPPitch;                  // scale * dS [row][key] bf16
+  float* xq = reinterpret_cast<float*>(st + kWinN * kWinPPitch);          // dq of the upper key half: [row tile][lane][16]
+  float* xkv = xq + kXq / 4;                                              // dv | dk of the upper row half: [key tile][lane][32]
+  const int head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int rt = wave & 3, hs = wave >> 2;                      // row tile (key tile on the key side); key half (row half)
+  const int kh = lane >> 5;
+  const long tok = 3L * heads * HD;
+  const int C = heads * HD;
+  const int i = rt * 32 + (lane & 31);
+  const bool row_ok = i < n;
+  const float scale2 = scale * kLog2e;
+  const float* bias_row = bias + (static_cast<long>(head) * n + (row_ok ? i : 0)) * kWinN;
+  const float inv_scale = 1.f / scale, neg = -100.f * inv_scale;
+  float db[2][16];
+  f32x16 cb[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    win_bias_init(bias_row, 2 * hs + tt, kh, n, inv_scale, row_ok, cb[tt]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) db[tt][r] = 0.f;
+  }
+  struct WinPre {
+    typename T::Regs a, b;            // hs 0: q, k;  hs 1: v, dout
+    u32x4 o4[HD / 16], d4[HD / 16];
+    unsigned mw[2];
+    float lse;
+  };
+  auto fetch_window = [&](int w) {
+    WinPre pf;
+    const unsigned short* base = qkv + static_cast<long>(w) * n * tok + head * HD;
+    if (hs == 0) {
+      pf.a = T::fetch(base, tok, n);
+      pf.b = T::fetch(base + heads * HD, tok, n);
+    } else {
+      pf.a = T::fetch(base + 2 * heads * HD, tok, n);
+      pf.b = T::fetch(dout + static_cast<long>(w) * n * C + head * HD, C, n);
+    }
+    pf.mw[0] = pf.mw[1] = 0u;
+    pf.lse = INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) { pf.o4[ks] = u32x4{0u, 0u, 0u, 0u}; pf.d4[ks] = u32x4{0u, 0u, 0u, 0u}; }
+    if (row_ok) {
+      const unsigned short* orow = out + (static_cast<long>(w) * n + i) * C + head * HD;
+      const unsigned short* drow = dout + (static_cast<long>(w) * n + i) * C + head * HD;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        pf.o4[ks] = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * kh);
+        pf.d4[ks] = *reinterpret_cast<const u32x4*>(drow + 16 * ks + 8 * kh);
+      }
+      pf.lse = lse2[(static_cast<long>(w) * heads + head) * n + i];
+      if (maskbits != nullptr) {
+        const uint2 m2 = *reinterpret_cast<const uint2*>(maskbits + (static_cast<long>(w % n_win) * n + i) * 4 + 2 * hs);
+        pf.mw[0] = m2.x; pf.mw[1] = m2.y;
+      }
+    }
+    return pf;
+  };
+  WinPre pre;
+  if (static_cast<int>(blockIdx.x) < windows) pre = fetch_window(blockIdx.x);
+  for (int w = blockIdx.x; w < windows; w += gridDim.x) {
+    if (hs == 0) { T::put(qt, pre.a); T::put(kt, pre.b); }
+    else { T::put(vt, pre.a); T::put(dt, pre.b); }
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dpart += bf16_lo(pre.o4[ks][e]) * bf16_lo(pre.d4[ks][e]) + bf16_hi(pre.o4[ks][e]) * bf16_hi(pre.d4[ks][e]);
+    const float dsum_s = (dpart + other_half(dpart)) * scale;
+    const float lse_i = pre.lse;
+    const unsigned mw[2] = {pre.mw[0], pre.mw[1]};
+    __syncthreads();
+    if (w + static_cast<int>(gridDim.x) < windows) pre = fetch_window(w + gridDim.x);
+
+    // ---- row side: P, dS of the wave's 32 rows x 64 keys; its half of dq; P and scale dS -> LDS
+    s16x8 qf[HD / 16], df[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      qf[ks] = T::rows(qt, lane, rt * 32, ks);
+      df[ks] = T::rows(dt, lane, rt * 32, ks);
+    }
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * hs + tt;
+      f32x16 sT = cb[tt], dpT;
+      if (maskbits != nullptr && wave_any(mw[tt] != 0u)) win_mask_apply(mw[tt], kh, neg, sT);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dpT[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        sT = mfma(T::rows(kt, lane, 32 * t, ks), qf[ks], sT);
+        dpT = mfma(T::rows(vt, lane, 32 * t, ks), df[ks], dpT);
+      }
+      unsigned ppk[8], dpk[8];
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        float pr[2], dsr[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 2 * e2 + e;
+          pr[e] = fast_exp2(__builtin_fmaf(sT[r], scale2, -lse_i));
+          dsr[e] = pr[e] * __builtin_fmaf(dpT[r], scale, -dsum_s);
+          db[tt][r] += dsr[e];
+        }
+        ppk[e2] = pack_bf16(pr[0], pr[1]);
+        dpk[e2] = pack_bf16(dsr[0], dsr[1]);
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int off = i * kWinPPitch + (((8 * t + 2 * qd + kh) ^ win_p_swz(i)) << 3);
+        *reinterpret_cast<u32x2*>(pt + off) = u32x2{ppk[2 * qd], ppk[2 * qd + 1]};
+        *reinterpret_cast<u32x2*>(st + off) = u32x2{dpk[2 * qd], dpk[2 * qd + 1]};
+      }
+      s16x8 dsf[2];
+      packed_column_to_b_frags(dpk, dsf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dq = mfma(T::cols(kt, lane, 32 * t + 16 * j), dsf[j], dq);
+    }
+    float4* xq4 = reinterpret_cast<float4*>(xq) + (rt * 64 + lane) * 4;
+    if (hs == 1) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) xq4[qd] = float4{dq[4 * qd], dq[4 * qd + 1], dq[4 * qd + 2], dq[4 * qd + 3]};
+    }
+    __syncthreads();
+    if (hs == 0) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 o = xq4[qd];
+        dq[4 * qd] += o.x; dq[4 * qd + 1] += o.y; dq[4 * qd + 2] += o.z; dq[4 * qd + 3] += o.w;
+      }
+      if (row_ok) win_store<HD>(dqkv + (static_cast<long>(w) * n + i) * tok + head * HD, dq, kh);
+    }
+
+    // ---- key side: the wave's 32 keys x 64 rows (rt is the key tile here, hs the row half)
+    f32x16 dv, dk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const int jr = 4 * hs + j4;
+      dv = mfma(T::cols(dt, lane, 16 * jr), wp_frag(pt, lane, 16 * jr, rt * 32), dv);
+      dk = mfma(T::cols(qt, lane, 16 * jr), wp_frag(st, lane, 16 * jr, rt * 32), dk);
+    }
+    float4* xkv4 = reinterpret_cast<float4*>(xkv) + (rt * 64 + lane) * 8;
+    if (hs == 1) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        xkv4[qd] = float4{dv[4 * qd], dv[4 * qd + 1], dv[4 * qd + 2], dv[4 * qd + 3]};
+        xkv4[4 + qd] = float4{dk[4 * qd], dk[4 * qd + 1], dk[4 * qd + 2], dk[4 * qd + 3]};
+      }
+    }
+    __syncthreads();
+    if (hs == 0) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 a = xkv4[qd], b = xkv4[4 + qd];
+        dv[4 * qd] += a.x; dv[4 * qd + 1] += a.y; dv[4 * qd + 2] += a.z; dv[4 * qd + 3] += a.w;
+        dk[4 * qd] += b.x; dk[4 * qd + 1] += b.y; dk[4 * qd + 2] += b.z; dk[4 * qd + 3] += b.w;
+      }
+      if (row_ok) {                                                   // here i is the lane's KEY
+        unsigned short* dst = dqkv + (static_cast<long>(w) * n + i) * tok + head * HD;
+        win_store<HD>(dst + heads * HD, dk, kh);
+        win_store<HD>(dst + 2 * heads * HD, dv, kh);
+      }
+    }
+    // (no barrier here: the next window's tiles are put into kt .. dt, which every wave finished reading before the barrier
+    // above; pt / st are rewritten only after the next window's first barrier; xq / xkv only after its second / third)
+  }
+  if (row_ok) {
+    float* drow = dbias + (static_cast<long>(head) * n + i) * kWinN;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * (2 * hs + tt) + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (key < n) atomicAdd(drow + key, db[tt][r] * inv_scale);
+      }
+  }
+}
+
 }  // namespace transoar
 
 using namespace transoar;
@@ -1018,7 +1220,10 @@ extern "C" int transoar_win_attn_backward(const void* qkv, const void* out, cons
   auto ds = static_cast<const unsigned short*>(dout);
   auto dq = static_cast<unsigned short*>(dqkv);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  // head dimension 16: eight waves per workgroup (0.86 -> 0.77 ms on the stage-0 shape); TRANSOAR_WIN_BWD8=0 keeps four
+  static const bool eight = [] { const char* e = getenv("TRANSOAR_WIN_BWD8"); return !(e && e[0] == '0'); }();
   if (head_dim == 32) hipLaunchKernelGGL(win_attn_bwd<32>, dim3(per_head, heads), dim3(256), 0, st, qs, os, ds, lse2, bias, maskbits, dq, dbias, n, heads, n_win, windows, scale);
+  else if (eight) hipLaunchKernelGGL(win_attn_bwd8<16>, dim3(per_head, heads), dim3(512), 0, st, qs, os, ds, lse2, bias, maskbits, dq, dbias, n, heads, n_win, windows, scale);
   else hipLaunchKernelGGL(win_attn_bwd<16>, dim3(per_head, heads), dim3(256), 0, st, qs, os, ds, lse2, bias, maskbits, dq, dbias, n, heads, n_win, windows, scale);
   return static_cast<int>(hipGetLastError());
 }
