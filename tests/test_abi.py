@@ -129,7 +129,7 @@ def test_sampling_head_and_colsum_argument_errors():
     qb = tok.transoar_pos_query_backward
     qb.argtypes = [p, p, i, lg, p, lg, i, p]
     assert qb(p16, p16, 4, 8, None, 16, 384, None) == -1
-    assert tok.transoar_pos_query_partial_rows() > 0 and tok.transoar_tokens_abi_version() == 6
+    assert tok.transoar_pos_query_partial_rows() > 0 and tok.transoar_tokens_abi_version() == 7
     c = rows.transoar_rows_colsum
     c.argtypes = [p, p, p, lg, i, p]
     assert c(None, p16, p16, 8, 8, None) == -1
@@ -140,6 +140,40 @@ def test_sampling_head_and_colsum_argument_errors():
     assert cs(None, p16, 8, 8, 1, None) == -1
     assert cs(p16, p16, 8, 12, 1, None) == -2                              # bf16: cols not a multiple of 8
     assert cs(p16, p16, 8, 6, 0, None) == -2                               # fp32: cols not a multiple of 4
+    # round 5: the LayerNorm-rows backward takes the shortcut's gradient (NULL = none); the merge gather with its residual
+    lb = tok.transoar_ln_rows_backward
+    lb.argtypes = [p, p, i, p, p, p, p, p, p, lg, i, p]
+    assert lb(p16, p16, 1, p16, p16, p16, None, None, p16, 8, 48, None) == -1      # dx is required, dx_add is not
+    assert lb(p16, p16, 1, p16, p16, p16, None, p16, p16, 8, 52, None) == -2       # cols not a multiple of 8
+    ga = rows.transoar_rows_gather_axpy
+    ga.argtypes = [p, p, p, p, p, i, lg, lg, i, p]
+    assert ga(None, p16, None, None, p16, 1, 8, 8, 96, None) == -1
+    assert ga(p16, p16, None, None, p16, 1, 8, 8, 100, None) == -2                 # rows not a multiple of 16 bytes
+
+
+def test_round5_gemm_entries_argument_errors():
+    """transoar_gemm_nt_gelu (include/transoar_gemm.h) and transoar_linear_wgrad_bias (include/transoar_convgemm.h)."""
+    gemm = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_gemm.so"))
+    conv = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_convgemm.so"))
+    attn = ctypes.CDLL(os.path.join(ROOT, "transoar_amd", "libtransoar_attn.so"))
+    buf = (ctypes.c_char * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    p, i, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    g = gemm.transoar_gemm_nt_gelu
+    g.argtypes = [p] * 5 + [i] * 7 + [p]
+    assert g(p16, p16, None, p16, None, 8, 8, 8, 8, 8, 8, 1, None) == -1           # aux is required
+    assert g(p16, p16, None, p16, p16, 8, 8, 12, 12, 12, 8, 1, None) == -2         # K not a multiple of 8
+    assert g(p16, p16, None, p16, p16, 8, 8, 8, 8, 8, 8, 3, None) == -2            # unknown mode
+    assert g(p16, p16, None, p16, p16 + 2, 8, 8, 8, 8, 8, 8, 2, None) == -4
+    assert gemm.transoar_gemm_abi_version() == 4
+    w = conv.transoar_linear_wgrad_bias
+    w.argtypes = [p] * 6 + [i] * 4 + [p]
+    assert w(p16, p16, p16, p16, None, p16, 1024, 48, 144, 1, None) == -1
+    assert w(p16, p16, p16, p16, p16, p16, 1024, 128, 144, 1, None) == -2          # no padding column for the ones
+    wf = attn.transoar_win_attn_forward
+    wf.argtypes = [p] * 5 + [i] * 5 + [f32, p]
+    assert wf(p16, p16, None, p16, p16, 1, 1, 125, 3, 16, 0.0, None) == -2         # scale must be positive
+    assert wf(p16, p16, None, p16, p16, 1, 1, 125, 3, 24, 0.25, None) == -2        # head dimension 16 or 32
 
 
 def test_convgemm_and_fused_gather_argument_errors():
