@@ -66,8 +66,10 @@ def stream_kind(x, w, out_dtype=None, relu=False):
     n = w.shape[0]
     if not (x.is_contiguous() and w.is_contiguous() and m >= 16384):
         return None
-    if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE):
-        return "k384"            # (384 x 384: the tiled kernel measures 0.149 ms against 0.158, profiles/r04_gemm_bench.jsonl)
+    if k == 384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE) and (n <= 2048 or relu):
+        # (384 x 384: the tiled kernel measures 0.149 ms against 0.158, profiles/r04_gemm_bench.jsonl; 384 -> 3072, the FPN's
+        # transposed convolution as a product: 0.77 against 0.83, profiles/r05_gemm_bench.jsonl)
+        return "k384"
     if STREAM_N384 and n == 384 and k % 32 == 0 and k != 384 and (m + 128) * k * 2 < 0xffffffff:
         return "n384"            # (off by default: 0.315 ms on 234 000 x 1024 -> 384 against the tiled kernel's 0.269)
     return None
@@ -78,7 +80,7 @@ def k384_takes(m, n):
     operands?  The shape part of its answer, for callers that decide before the bf16 operands exist; `gated` products
     (linear_gate) also read an (m, n) bf16 gate through a 32-bit byte offset."""
     return bool(STREAM and m >= 16384 and n % 64 == 0 and n * 768 < 0x7ffffff0 and (n != 384 or STREAM_SQUARE)
-                and (m + 32) * n * 2 < 0xffffffff)
+                and (m + 32) * n * 2 < 0xffffffff)          # (callers with fused epilogues: n = 1024 in the shipped configurations)
 
 
 def linear_nt(x, w, bias=None, relu=False, out_dtype=None):
@@ -158,7 +160,7 @@ def linear_relu_dropout(x, w, bias, seed, keep_prob):
     """dropout(relu(x @ w.T + bias)) in one kernel (K = 384 streaming GEMM with the seeded mask of tokens.relu_dropout in
     its epilogue).  x (M, 384), w (N, 384) bf16 dense, bias fp32 or None, seed: device int32 tensor (tokens.dropout_seed)
     or None (no dropout)."""
-    if stream_kind(x, w) != "k384":
+    if stream_kind(x, w, relu=True) != "k384":
         raise RuntimeError("linear_relu_dropout: needs the K = 384 streaming kernel (dense bf16 operands, >= 16384 rows)")
     m, n = x.shape[0], w.shape[0]
     out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
@@ -222,7 +224,7 @@ def wgrad384(gy, x, with_bias=False):
 def linear_gate(x, w, gate, scale):
     """gate > 0 ? (x @ w.T) * scale : 0 in one kernel: x (M, 384), w (N, 384), gate (M, N) bf16 dense -- the data gradient of
     the FFN's second layer with the gradient of dropout(relu(.)) in the GEMM's epilogue (gate = the saved hidden tensor)."""
-    if stream_kind(x, w) != "k384" or gate.shape != (x.shape[0], w.shape[0]) or gate.dtype != torch.bfloat16 or not gate.is_contiguous():
+    if stream_kind(x, w, relu=True) != "k384" or gate.shape != (x.shape[0], w.shape[0]) or gate.dtype != torch.bfloat16 or not gate.is_contiguous():
         raise RuntimeError("linear_gate: needs the K = 384 streaming kernel (dense bf16 operands, >= 16384 rows) and a dense bf16 gate")
     m, n = x.shape[0], w.shape[0]
     if (m + 32) * n * 2 >= 0xffffffff:

@@ -20,6 +20,7 @@ is assembled once per block.  Padding tokens are zero vectors that take part in 
 the reference (it pads AFTER norm1, encoder_blocks.py:158-164).
 """
 import itertools
+import os
 
 import torch
 import torch.nn.functional as F
@@ -29,7 +30,7 @@ from . import rows, win_attn
 from . import tokens as fused_tokens
 from .token_linear import gelu_mlp, gelu_mlp_usable, token_linear
 
-MIN_TOKENS = 8192            # token matrices at least this tall take the hand-written GEMMs (token_linear)
+MIN_TOKENS = int(os.environ.get("TRANSOAR_SWIN_MIN_TOKENS", "8192"))            # token matrices at least this tall take the hand-written GEMMs (token_linear)
 
 
 def _fast(x):
