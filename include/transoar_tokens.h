@@ -104,7 +104,7 @@ int transoar_sampling_head_backward(const float* g_loc, const float* g_attn, con
                                     void* g_proj, long tokens, int M, int L, int P, void* hip_stream);
 
 /*
- * LayerNorm over short rows (cols a multiple of 8, 8 <= cols <= 512): the norms of the Swin encoder stages
+ * LayerNorm over short rows (cols a multiple of 8, 8 <= cols <= 1536): the norms of the Swin encoder stages
  * (transoar/models/backbones/encoder_blocks.py:143-327, nn.LayerNorm over 48 .. 384 channels of 10^5 .. 10^6 tokens).
  *   forward:  y16 (rows, cols) bf16 = LayerNorm(x) * weight + bias, x bf16 or fp32; mean / rstd (rows) fp32 are kept for
  *             the backward

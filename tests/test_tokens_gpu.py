@@ -243,7 +243,7 @@ def test_pos_query_matches_the_eager_chain(cols):
     assert (gle - gle_ref).abs().max().item() <= 1e-4 * gle_ref.abs().max().item()
 
 
-@pytest.mark.parametrize("cols", [48, 96, 192, 384, 512, 8])
+@pytest.mark.parametrize("cols", [48, 96, 192, 384, 512, 8, 768, 1536, 1000])
 @pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float32])
 def test_layernorm_rows_matches_torch(cols, xdt):
     """Short-row LayerNorm (Swin stages: 48 .. 384 channels) against F.layer_norm in fp32: output, input gradient and the

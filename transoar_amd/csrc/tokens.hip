@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void sampling_head_bwd_p16(const float* __rest
 
 
 // ---------------------------------------------------------------------------
-// LayerNorm over SHORT rows (48 .. 512 channels, a multiple of 8): the norm1 / norm2 / patch-merge norms of the Swin
+// LayerNorm over SHORT rows (48 .. 512 channels, a multiple of 8; up to 1536 on the *_wide kernels below): the norm1 / norm2 / patch-merge norms of the Swin
 // encoder stages (transoar/models/backbones/encoder_blocks.py:143-327, nn.LayerNorm over 48 / 96 / 192 / 384 channels
 // of 10^5 .. 10^6 tokens).  aten's kernels take 0.4 ms per pass on the 1.6 M x 48 fp32 rows of stage 2 (23 ms per step);
 // add_ln_* above needs a multiple of 128 columns.  Here a GROUP of G lanes (the next power of two >= cols / 8) owns a row,
@@ -684,6 +684,131 @@ __global__ __launch_bounds__(256) void ln_rows_bwd(const uint4* __restrict__ g16
     *reinterpret_cast<float4*>(pr + c0 + 4) = float4{dw[4], dw[5], dw[6], dw[7]};
     *reinterpret_cast<float4*>(pr + cols + c0) = float4{db[0], db[1], db[2], db[3]};
     *reinterpret_cast<float4*>(pr + cols + c0 + 4) = float4{db[4], db[5], db[6], db[7]};
+  }
+}
+
+// The same two kernels for 512 < cols <= 1536 (the patch-merge norms of the later Swin stages: 8 x 96 = 768 and 8 x 192 = 1536
+// channels): one row per wave, up to three 8-channel pieces per lane (columns 8 lane + 512 ch).
+constexpr int kLnWideCh = 3;
+template <bool XBF>
+__global__ __launch_bounds__(256) void ln_rows_fwd_wide(const void* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
+                                                        float eps, uint4* __restrict__ y16, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[kLnWideCh][8];
+  float s = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < kLnWideCh; ++ch) {
+    const int c0 = lane * 8 + 512 * ch;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[ch][i] = 0.f;
+    if (c0 < cols) ln_load8<XBF>(x, row, cols, c0, v[ch]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[ch][i];
+  }
+  const float mean = group_sum<64>(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < kLnWideCh; ++ch)
+    if (lane * 8 + 512 * ch < cols) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[ch][i] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(group_sum<64>(q) / cols + eps);
+#pragma unroll
+  for (int ch = 0; ch < kLnWideCh; ++ch) {
+    const int c0 = lane * 8 + 512 * ch;
+    if (c0 >= cols) continue;
+    const float4 w0 = *reinterpret_cast<const float4*>(weight + c0), w1 = *reinterpret_cast<const float4*>(weight + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (v[ch][i] - mean) * rstd * ww[i] + bb[i];
+    y16[(row * cols + c0) >> 3] = uint4{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <bool XBF>
+__global__ __launch_bounds__(256) void ln_rows_bwd_wide(const uint4* __restrict__ g16, const void* __restrict__ x, const float* __restrict__ weight,
+                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                        const void* __restrict__ dx_add, void* __restrict__ dx,
+                                                        float* __restrict__ partials, long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  float ww[kLnWideCh][8], dw[kLnWideCh][8], db[kLnWideCh][8];
+#pragma unroll
+  for (int ch = 0; ch < kLnWideCh; ++ch) {
+    const int c0 = lane * 8 + 512 * ch;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ww[ch][i] = 0.f; dw[ch][i] = 0.f; db[ch][i] = 0.f; }
+    if (c0 < cols) {
+      const float4 w0 = *reinterpret_cast<const float4*>(weight + c0), w1 = *reinterpret_cast<const float4*>(weight + c0 + 4);
+      ww[ch][0] = w0.x; ww[ch][1] = w0.y; ww[ch][2] = w0.z; ww[ch][3] = w0.w; ww[ch][4] = w1.x; ww[ch][5] = w1.y; ww[ch][6] = w1.z; ww[ch][7] = w1.w;
+    }
+  }
+  const long wave_id = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long n_waves = static_cast<long>(gridDim.x) * 4;
+  for (long row = wave_id; row < rows; row += n_waves) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[kLnWideCh][8], gw[kLnWideCh][8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < kLnWideCh; ++ch) {
+      const int c0 = lane * 8 + 512 * ch;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const bool on = c0 < cols;
+      if (on) {
+        ln_load8<XBF>(x, row, cols, c0, v);
+        const uint4 q = g16[(row * cols + c0) >> 3];
+        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g[2 * i] = bf16_lo(w4[i]); g[2 * i + 1] = bf16_hi(w4[i]); }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xh[ch][i] = on ? (v[i] - mean) * rstd : 0.f;
+        gw[ch][i] = g[i] * ww[ch][i];
+        s1 += gw[ch][i];
+        s2 += gw[ch][i] * xh[ch][i];
+        dw[ch][i] += g[i] * xh[ch][i];
+        db[ch][i] += g[i];
+      }
+    }
+    const float c1 = group_sum<64>(s1) / cols, c2 = group_sum<64>(s2) / cols;
+#pragma unroll
+    for (int ch = 0; ch < kLnWideCh; ++ch) {
+      const int c0 = lane * 8 + 512 * ch;
+      if (c0 >= cols) continue;
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rstd * (gw[ch][i] - c1 - xh[ch][i] * c2);
+      if (dx_add != nullptr) {
+        float a[8];
+        ln_load8<XBF>(dx_add, row, cols, c0, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += a[i];
+      }
+      if (XBF) {
+        reinterpret_cast<uint4*>(dx)[(row * cols + c0) >> 3] =
+            uint4{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+      } else {
+        float4* po = reinterpret_cast<float4*>(static_cast<float*>(dx) + row * cols + c0);
+        po[0] = float4{o[0], o[1], o[2], o[3]};
+        po[1] = float4{o[4], o[5], o[6], o[7]};
+      }
+    }
+  }
+  float* pr = partials + wave_id * (2L * cols);
+#pragma unroll
+  for (int ch = 0; ch < kLnWideCh; ++ch) {
+    const int c0 = lane * 8 + 512 * ch;
+    if (c0 >= cols) continue;
+    *reinterpret_cast<float4*>(pr + c0) = float4{dw[ch][0], dw[ch][1], dw[ch][2], dw[ch][3]};
+    *reinterpret_cast<float4*>(pr + c0 + 4) = float4{dw[ch][4], dw[ch][5], dw[ch][6], dw[ch][7]};
+    *reinterpret_cast<float4*>(pr + cols + c0) = float4{db[ch][0], db[ch][1], db[ch][2], db[ch][3]};
+    *reinterpret_cast<float4*>(pr + cols + c0 + 4) = float4{db[ch][4], db[ch][5], db[ch][6], db[ch][7]};
   }
 }
 
@@ -867,8 +992,14 @@ static int ln_group(int cols) {
 extern "C" int transoar_ln_rows_forward(const void* x, int x_is_bf16, const float* weight, const float* bias, float eps, void* y16,
                                         float* mean, float* rstd, long rows, int cols, void* hip_stream) {
   if (!x || !weight || !bias || !y16 || !mean || !rstd) return TRANSOAR_TOK_ERR_NULL;
-  if (rows <= 0 || cols < 8 || cols > 512 || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
+  if (rows <= 0 || cols < 8 || cols > 512 * kLnWideCh || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (cols > 512) {
+    const dim3 wgrid(static_cast<unsigned>((rows + 3) / 4));
+    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_fwd_wide<true>), wgrid, dim3(256), 0, st, x, weight, bias, eps, static_cast<uint4*>(y16), mean, rstd, rows, cols);
+    else hipLaunchKernelGGL((ln_rows_fwd_wide<false>), wgrid, dim3(256), 0, st, x, weight, bias, eps, static_cast<uint4*>(y16), mean, rstd, rows, cols);
+    return static_cast<int>(hipGetLastError());
+  }
   const int g = std::max(8, ln_group(cols));
   const long rows_per_block = 4L * (64 / g);
   const dim3 grid(static_cast<unsigned>((rows + rows_per_block - 1) / rows_per_block));
@@ -885,8 +1016,13 @@ extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_i
                                          const float* rstd, const void* dx_add, void* dx, float* partials, long rows, int cols,
                                          void* hip_stream) {
   if (!g16 || !x || !weight || !mean || !rstd || !dx || !partials) return TRANSOAR_TOK_ERR_NULL;
-  if (rows <= 0 || cols < 8 || cols > 512 || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
+  if (rows <= 0 || cols < 8 || cols > 512 * kLnWideCh || (cols & 7)) return TRANSOAR_TOK_ERR_DIM;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (cols > 512) {
+    if (x_is_bf16) hipLaunchKernelGGL((ln_rows_bwd_wide<true>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx_add, dx, partials, rows, cols);
+    else hipLaunchKernelGGL((ln_rows_bwd_wide<false>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx_add, dx, partials, rows, cols);
+    return static_cast<int>(hipGetLastError());
+  }
   const int g = std::max(8, ln_group(cols));
   LN_DISPATCH(g, {
     if (x_is_bf16) hipLaunchKernelGGL((ln_rows_bwd<G, true>), dim3(kLnBlocks), dim3(256), 0, st, static_cast<const uint4*>(g16), x, weight, mean, rstd, dx_add, dx, partials, rows, cols);

@@ -413,7 +413,7 @@ class _LayerNormRowsFork(torch.autograd.Function):
 
 def layernorm_rows_usable(x, norm):
     cols = x.shape[-1]
-    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and 8 <= cols <= 512 and cols % 8 == 0
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and 8 <= cols <= 1536 and cols % 8 == 0
             and tuple(norm.normalized_shape) == (cols,) and norm.elementwise_affine and norm.bias is not None
             and x.data_ptr() % 16 == 0)
 
