@@ -1053,16 +1053,18 @@ __global__ __launch_bounds__(512) void win_attn_bwd8(
 #pragma unroll
       for (int j = 0; j < 2; ++j) dq = mfma(T::cols(kt, lane, 32 * t + 16 * j), dsf[j], dq);
     }
-    float4* xq4 = reinterpret_cast<float4*>(xq) + (rt * 64 + lane) * 4;
+    // (piece-major, lane-minor: the 8 lanes of a 16-byte access group touch 128 contiguous bytes; lane-major cost 58 % of the
+    // kernel's LDS cycles in bank conflicts)
+    float4* xq4 = reinterpret_cast<float4*>(xq) + rt * 256 + lane;
     if (hs == 1) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) xq4[qd] = float4{dq[4 * qd], dq[4 * qd + 1], dq[4 * qd + 2], dq[4 * qd + 3]};
+      for (int qd = 0; qd < 4; ++qd) xq4[qd * 64] = float4{dq[4 * qd], dq[4 * qd + 1], dq[4 * qd + 2], dq[4 * qd + 3]};
     }
     __syncthreads();
     if (hs == 0) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const float4 o = xq4[qd];
+        const float4 o = xq4[qd * 64];
         dq[4 * qd] += o.x; dq[4 * qd + 1] += o.y; dq[4 * qd + 2] += o.z; dq[4 * qd + 3] += o.w;
       }
       if (row_ok) win_store<HD>(dqkv + (static_cast<long>(w) * n + i) * tok + head * HD, dq, kh);
@@ -1078,19 +1080,19 @@ __global__ __launch_bounds__(512) void win_attn_bwd8(
       dv = mfma(T::cols(dt, lane, 16 * jr), wp_frag(pt, lane, 16 * jr, rt * 32), dv);
       dk = mfma(T::cols(qt, lane, 16 * jr), wp_frag(st, lane, 16 * jr, rt * 32), dk);
     }
-    float4* xkv4 = reinterpret_cast<float4*>(xkv) + (rt * 64 + lane) * 8;
+    float4* xkv4 = reinterpret_cast<float4*>(xkv) + rt * 512 + lane;
     if (hs == 1) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        xkv4[qd] = float4{dv[4 * qd], dv[4 * qd + 1], dv[4 * qd + 2], dv[4 * qd + 3]};
-        xkv4[4 + qd] = float4{dk[4 * qd], dk[4 * qd + 1], dk[4 * qd + 2], dk[4 * qd + 3]};
+        xkv4[qd * 64] = float4{dv[4 * qd], dv[4 * qd + 1], dv[4 * qd + 2], dv[4 * qd + 3]};
+        xkv4[(4 + qd) * 64] = float4{dk[4 * qd], dk[4 * qd + 1], dk[4 * qd + 2], dk[4 * qd + 3]};
       }
     }
     __syncthreads();
     if (hs == 0) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const float4 a = xkv4[qd], b = xkv4[4 + qd];
+        const float4 a = xkv4[qd * 64], b = xkv4[(4 + qd) * 64];
         dv[4 * qd] += a.x; dv[4 * qd + 1] += a.y; dv[4 * qd + 2] += a.z; dv[4 * qd + 3] += a.w;
         dk[4 * qd] += b.x; dk[4 * qd + 1] += b.y; dk[4 * qd + 2] += b.z; dk[4 * qd + 3] += b.w;
       }
