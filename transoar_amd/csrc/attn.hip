@@ -482,16 +482,19 @@ TRANSOAR_ATTN_KERNEL void roi_attn_bwd_k(
   for (int ct = 0; ct < kCT; ++ct)
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd)
-      *reinterpret_cast<u32x2*>(ob + (lane & 31) * kRowBytes + (32 * ct + 8 * qd + 4 * kh) * 2) =
+      // the 48 16-byte pieces of row r sit at piece ^ (r & 15): 768-byte rows put all 16 rows of a store's lane group on the
+      // same banks (16-way: 46 % of this kernel's LDS cycles were conflict cycles)
+      *reinterpret_cast<u32x2*>(ob + (lane & 31) * kRowBytes + (((4 * ct + qd) ^ (lane & 15)) << 4) + 8 * kh) =
           u32x2{pack_bf16(acc[ct][4 * qd], acc[ct][4 * qd + 1]), pack_bf16(acc[ct][4 * qd + 2], acc[ct][4 * qd + 3])};
   // (a wave's LDS operations execute in order: its reads below see its writes above; no other wave touches this region)
 #pragma unroll
   for (int i = 0; i < 24; ++i) {
     const int off = i * 1024 + lane * 16;
     const int kr = ((off >> 8) * 171) >> 9;
+    const int piece = (off >> 4) - 48 * kr;
     if (key0 + kr < L)
       *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(out_g + static_cast<long>(key0) * kC) + off) =
-          *reinterpret_cast<const u32x4*>(ob + off);
+          *reinterpret_cast<const u32x4*>(ob + kr * kRowBytes + ((piece ^ (kr & 15)) << 4));
   }
 }
 
