@@ -14,10 +14,11 @@ def _ref(x, w, bias, relu):
     return y.relu() if relu else y
 
 
-# (the last five: the streaming kernels of csrc/gemm_stream.hip -- K = 384 / N = 384, >= 16 384 dense rows; odd heights)
+# (234000 .. 100001 rows: the streaming kernels of csrc/gemm_stream.hip -- K = 384 / N = 384, >= 16 384 dense rows; odd heights;
+# the last four: at most 64 output columns -- the 128 x 64 tile of the Swin blocks' narrow products, bf16)
 @pytest.mark.parametrize("m,k,n", [(1000, 384, 384), (4099, 1024, 384), (300, 384, 1024), (777, 64, 100), (128, 8, 4),
                                     (234000, 384, 384), (234000, 384, 1024), (234000, 1024, 384), (100001, 384, 576),
-                                    (100001, 768, 384)])
+                                    (100001, 768, 384), (50001, 192, 48), (30000, 48, 48), (9000, 144, 64), (40007, 96, 60)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_nt_matches_fp32_matmul(m, k, n, dt, monkeypatch):
     if not torch.cuda.is_available():
@@ -33,7 +34,7 @@ def test_gemm_nt_matches_fp32_matmul(m, k, n, dt, monkeypatch):
         want = _ref(x, w, bias, relu)
         got = gemm.linear_nt(x, w, bias, relu)
         assert got.dtype == dt and got.shape == (m, n)
-        if m >= 16384 and dt == torch.bfloat16 and not (k == 384 and n == 384):
+        if m >= 16384 and dt == torch.bfloat16 and (k == 384) != (n == 384):
             assert gemm.stream_kind(x, w) == ("k384" if k == 384 else "n384")
         assert float((got.float() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6
     got32 = gemm.linear_nt(x, w, b, False, out_dtype=torch.float32)

@@ -111,13 +111,13 @@ __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
 // backward on the way out (C = (A B^T) * gelu'(aux)).  2 and 3 work on the bf16-ROUNDED product, in the row-store phase: the
 // rounding points of a GEMM followed by torch's gelu / gelu_backward kernels, minus their passes over the hidden tensor.
 template <bool F16, bool OUT_F32, int EPI, int KT_STATIC, int WN>
-__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
+__global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cout, unsigned short* __restrict__ aux, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles,
     int tiles_n) {
   constexpr bool RELU = EPI == 1;
   static_assert(EPI < 2 || (!F16 && !OUT_F32), "the GELU epilogues are bf16 in, bf16 out");
-  constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (2 or 4), 2 along M
+  constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (1, 2 or 4), 2 along M
   constexpr int kStageBytes = kATileBytes + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][kStageBytes];      // [stage]: A tile, then B tile
   // Tiles of this workgroup: XCD x = block & 7 owns the contiguous eighth [x per, (x + 1) per) of the tiles (n fastest);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 2) void gemm_nt_kernel(
   // DPRE (round 5, second half): the run-time K loop does the same with ONE step of look-ahead and a stage index that is
   // carried from tile to tile -- the Swin stages' products have K = 48 .. 192, i.e. one to three K steps per tile, and ran
   // one workgroup per tile: load latency, a handful of MFMAs, epilogue, nothing overlapping.
-  constexpr bool DPRE = KT_STATIC == 0 && WN == 2;
+  constexpr bool DPRE = KT_STATIC == 0 && WN <= 2;
   constexpr bool PERSIST = (KT_STATIC > 0 && (KT_STATIC % 2) == 0) || DPRE;
   const long per = (n_tiles + 7) >> 3;
   const long xend = min((static_cast<long>(blockIdx.x & 7) + 1) * per, n_tiles);
@@ -424,6 +424,18 @@ int launch(const void* A, const void* B, const float* bias, void* C, void* aux, 
                          ldc, n_tiles, tiles_n);                                                                            \
   } while (0)
   if constexpr (!F16 && !OUT_F32) {
+    static const int narrow_max = [] { const char* e = getenv("TRANSOAR_GEMM_NARROW_MAX"); return e ? atoi(e) : 64; }();
+    if (epi == 0 && kts == 0 && N <= narrow_max) {
+      // up to 64 output columns (the Swin blocks' 48-wide products): 128 x 64 tiles on two waves -- the 128-wide tile left
+      // half of its waves without a column to store and DMA-ed 64 out-of-range weight rows per K step; three workgroups per CU
+      const int tn = (N + 63) / 64;
+      const long nt = static_cast<long>(tiles_m) * tn;
+      long px = (nt + 7) / 8;
+      if (persist_wgs >= 8 && px > persist_wgs * 3 / 16) px = persist_wgs * 3 / 16;
+      hipLaunchKernelGGL((gemm_nt_kernel<false, false, 0, 0, 1>), dim3(static_cast<unsigned>(px * 8)), dim3(128), 0, st, a, b, bias, C, x, M, N, K,
+                         lda, ldb, ldc, nt, tn);
+      return static_cast<int>(hipGetLastError());
+    }
     if (epi == 2) { TRANSOAR_GEMM_LAUNCH(2, 0); return static_cast<int>(hipGetLastError()); }
     if (epi == 3) { TRANSOAR_GEMM_LAUNCH(3, 0); return static_cast<int>(hipGetLastError()); }
   }
