@@ -111,13 +111,13 @@ __device__ __forceinline__ long xcd_contiguous(long bid, long n) {
 // backward on the way out (C = (A B^T) * gelu'(aux)).  2 and 3 work on the bf16-ROUNDED product, in the row-store phase: the
 // rounding points of a GEMM followed by torch's gelu / gelu_backward kernels, minus their passes over the hidden tensor.
 template <bool F16, bool OUT_F32, int EPI, int KT_STATIC, int WN>
-__global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
+__global__ __launch_bounds__(128 * WN, (WN == 1 || (WN == 3 && EPI != 3)) ? 3 : 2) void gemm_nt_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cout, unsigned short* __restrict__ aux, int M, int N, int K, int lda, int ldb, int ldc, long n_tiles,
     int tiles_n) {
   constexpr bool RELU = EPI == 1;
   static_assert(EPI < 2 || (!F16 && !OUT_F32), "the GELU epilogues are bf16 in, bf16 out");
-  constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (1, 2 or 4), 2 along M
+  constexpr int BN = 64 * WN, kThreads = 128 * WN;          // WN waves along N (1, 2, 3 or 4), 2 along M
   constexpr int kStageBytes = kATileBytes + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][kStageBytes];      // [stage]: A tile, then B tile
   // Tiles of this workgroup: XCD x = block & 7 owns the contiguous eighth [x per, (x + 1) per) of the tiles (n fastest);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
   // DPRE (round 5, second half): the run-time K loop does the same with ONE step of look-ahead and a stage index that is
   // carried from tile to tile -- the Swin stages' products have K = 48 .. 192, i.e. one to three K steps per tile, and ran
   // one workgroup per tile: load latency, a handful of MFMAs, epilogue, nothing overlapping.
-  constexpr bool DPRE = KT_STATIC == 0 && WN <= 2;
+  constexpr bool DPRE = KT_STATIC == 0 && WN <= 3;
   constexpr bool PERSIST = (KT_STATIC > 0 && (KT_STATIC % 2) == 0) || DPRE;
   const long per = (n_tiles + 7) >> 3;
   const long xend = min((static_cast<long>(blockIdx.x & 7) + 1) * per, n_tiles);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
   // staging: thread -> (row, 16-byte piece) x 4 per operand.  The row's pieces past K read as zeros (offset
   // clamp below), rows past M / N are beyond the buffer: zeros as well.
   constexpr int RPP = kThreads / 8;                          // rows covered per pass of the block
-  constexpr int NA = BM / RPP, NB = BN / RPP;                // passes per operand tile: (4, 4) or (2, 4)
+  constexpr int NA = (BM + RPP - 1) / RPP, NB = BN / RPP;    // passes per operand tile: (4, 4), (2, 4), (8, 4); WN == 3: 3 (the last one 32 of 48 rows), 4
   const int s_piece = tid & 7, s_row = tid >> 3;             // rows s_row + RPP i
   // Round 5: the tiles go global -> LDS by DMA (round 2-4: through two register sets and 8 ds_write_b128 per thread and K
   // step, 13 cycles each on the CU's store path).  Lane L of wave w fills the PHYSICAL piece s_piece of row s_row + RPP i;
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
     const unsigned base = __builtin_amdgcn_readfirstlane(dst0 + static_cast<unsigned>(stage) * kStageBytes);
     const bool in_k = kt * BK + l_piece * 8 < K;             // last, partial K tile: pieces past K read as zeros (K % 8 == 0)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) dma16(ra, in_k ? a_off[i] : 0x80000000u, kbyte, base + i * (RPP * 128));
+    for (int i = 0; i < NA; ++i)
+      if (BM % RPP == 0 || s_row + RPP * i < BM)            // (WN == 3: waves 4, 5 have no row in the third pass -- wave-uniform)
+        dma16(ra, in_k ? a_off[i] : 0x80000000u, kbyte, base + i * (RPP * 128));
 #pragma unroll
     for (int i = 0; i < NB; ++i) dma16(rb, in_k ? b_off[i] : 0x80000000u, kbyte, base + kATileBytes + i * (RPP * 128));
   };
@@ -301,12 +303,15 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
   // through its own LDS region instead (row pitch padded by 16 bytes against bank conflicts) and leaves as
   // whole rows: 16 bytes per lane, 8 (4 for fp32) consecutive rows of 128 (256) contiguous bytes per store.
   // Rows of 128 bytes without padding (4 waves x 8 KiB = one stage), the 16-byte pieces XORed with row & 7.
-  unsigned char* stage = &lds[0][0] + (DPRE ? last : (XPRE ? 1 : 0)) * kStageBytes + wave * (64 * 128);
-  static_assert(2 * WN * 64 * 128 <= ((XPRE || DPRE) ? 1 : 2) * kStageBytes, "bf16 staging fits");
+  // WN == 3 (six waves, 128 x 192 tile): 6 x 8 KiB do not fit the one free 40-KiB stage -- the wave turns its result 32 rows
+  // at a time through a 4-KiB region instead
+  constexpr bool TWO_TURN = WN == 3;
+  constexpr int kTurnBytes = TWO_TURN ? 32 * 128 : 64 * 128;
+  unsigned char* stage = &lds[0][0] + (DPRE ? last : (XPRE ? 1 : 0)) * kStageBytes + wave * kTurnBytes;
+  static_assert(2 * WN * kTurnBytes <= ((XPRE || DPRE) ? 1 : 2) * kStageBytes, "bf16 staging fits");
   // (the main loop's last barrier has passed: every wave is done reading the operand tiles)
   if constexpr (!OUT_F32) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
+    auto write_half = [&](int b, int row0) {                          // rows b * 32 + fr of the wave tile -> turn rows row0 + fr
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -320,17 +325,17 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
             if (RELU) v = fmaxf(v, 0.f);
             h[e] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
           }
-          *reinterpret_cast<uint2*>(stage + (b * 32 + fr) * 128 + ((((nl >> 2) >> 1) ^ (fr & 7)) << 4) + ((nl >> 2) & 1) * 8) =
+          *reinterpret_cast<uint2*>(stage + (row0 + fr) * 128 + ((((nl >> 2) >> 1) ^ (fr & 7)) << 4) + ((nl >> 2) & 1) * 8) =
               uint2{static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16), static_cast<unsigned>(h[2]) | (static_cast<unsigned>(h[3]) << 16)};
         }
+    };
     // same wave wrote and reads: LDS operations of a wave are in order
     const int piece = lane & 7, r0 = lane >> 3;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    auto store_rows = [&](int it, int turn_row) {                     // wave-tile row it * 8 + r0, held at turn row turn_row
       const int row = it * 8 + r0;
       const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + piece * 8;
       if (m < M && n < N) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((piece ^ (row & 7)) << 4));
+        u32x4 v = *reinterpret_cast<const u32x4*>(stage + turn_row * 128 + ((piece ^ (turn_row & 7)) << 4));
         const long at = static_cast<long>(m) * ldc + n;
         const bool whole = n + 8 <= N && (ldc & 7) == 0;
         auto put = [&](unsigned short* dst, const u32x4& x) {
@@ -358,6 +363,19 @@ __global__ __launch_bounds__(128 * WN, WN == 1 ? 3 : 2) void gemm_nt_kernel(
             v[e] = pack2_bf16(gelu_grad_f(bf16_lo_f(v[e]), bf16_lo_f(h[e])), gelu_grad_f(bf16_hi_f(v[e]), bf16_hi_f(h[e])));
         }
         put(static_cast<unsigned short*>(Cout) + at, v);
+      }
+    };
+    if constexpr (!TWO_TURN) {
+      write_half(0, 0);
+      write_half(1, 32);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) store_rows(it, it * 8 + r0);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        write_half(b, 0);
+#pragma unroll
+        for (int it4 = 0; it4 < 4; ++it4) store_rows(b * 4 + it4, it4 * 8 + r0);
       }
     }
   } else {
@@ -434,6 +452,20 @@ int launch(const void* A, const void* B, const float* bias, void* C, void* aux, 
       if (persist_wgs >= 8 && px > persist_wgs * 3 / 16) px = persist_wgs * 3 / 16;
       hipLaunchKernelGGL((gemm_nt_kernel<false, false, 0, 0, 1>), dim3(static_cast<unsigned>(px * 8)), dim3(128), 0, st, a, b, bias, C, x, M, N, K,
                          lda, ldb, ldc, nt, tn);
+      return static_cast<int>(hipGetLastError());
+    }
+    static const bool use_192 = [] { const char* e = getenv("TRANSOAR_GEMM_TILE192"); return !(e && e[0] == '0'); }();
+    if (use_192 && kts == 0 && N > 128 && N <= 192) {
+      // 129 .. 192 output columns (the Swin blocks' 144- and 192-wide products): ONE 128 x 192 tile on six waves instead of a
+      // full and a mostly empty 128-wide one
+      long px = (static_cast<long>(tiles_m) + 7) / 8;
+      if (persist_wgs >= 8 && px > persist_wgs / 8) px = persist_wgs / 8;
+      const dim3 g3(static_cast<unsigned>(px * 8));
+      const long nt = tiles_m;
+      if (epi == 2) hipLaunchKernelGGL((gemm_nt_kernel<false, false, 2, 0, 3>), g3, dim3(384), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, ldc, nt, 1);
+      else if (epi == 3) hipLaunchKernelGGL((gemm_nt_kernel<false, false, 3, 0, 3>), g3, dim3(384), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, ldc, nt, 1);
+      else if (epi == 1) hipLaunchKernelGGL((gemm_nt_kernel<false, false, 1, 0, 3>), g3, dim3(384), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, ldc, nt, 1);
+      else hipLaunchKernelGGL((gemm_nt_kernel<false, false, 0, 0, 3>), g3, dim3(384), 0, st, a, b, bias, C, x, M, N, K, lda, ldb, ldc, nt, 1);
       return static_cast<int>(hipGetLastError());
     }
     if (epi == 2) { TRANSOAR_GEMM_LAUNCH(2, 0); return static_cast<int>(hipGetLastError()); }
