@@ -32,6 +32,7 @@ bash tools/profile_step.sh ${T}_swin --swin --no-refine > /dev/null 2>&1; cp $O/
 python tools/bench_roi_attn.py > $O/${T}_roi_attn_bench.jsonl 2>/dev/null; tail -3 $O/${T}_roi_attn_bench.jsonl | cut -c1-220
 (python tools/bench_win_attn.py; python tools/bench_win_attn.py --shifted) > $O/${T}_win_attn_bench.jsonl 2>/dev/null; head -2 $O/${T}_win_attn_bench.jsonl | cut -c1-220
 python tools/bench_gelu_mlp.py > $O/${T}_gelu_mlp_bench.jsonl 2>/dev/null; head -1 $O/${T}_gelu_mlp_bench.jsonl | cut -c1-300
-(cd /tmp; bash $OLDPWD/tools/pmc_any.sh $OLDPWD/$O/${T}_pmc_all "" -- python $OLDPWD/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_all.txt > $O/${T}_pmc_rank.txt; head -6 $O/${T}_pmc_rank.txt
-(cd /tmp; bash $OLDPWD/tools/pmc_any.sh $OLDPWD/$O/${T}_pmc_swin_all "" -- python $OLDPWD/bench.py --swin --no-refine --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_swin_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_swin_all.txt > $O/${T}_pmc_rank_swin.txt
+# (the raw counter files of these two passes are tens of MB: they stay in /tmp, only the per-kernel summaries come back)
+(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_all "" -- python $OLDPWD/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_all.txt > $O/${T}_pmc_rank.txt; head -6 $O/${T}_pmc_rank.txt
+(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_swin_all "" -- python $OLDPWD/bench.py --swin --no-refine --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_swin_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_swin_all.txt > $O/${T}_pmc_rank_swin.txt
 [ -n "${SKIP_CPU_STEP:-}" ] || { python bench.py --cpu-baseline-only --cpu-baseline-step > $O/${T}_cpu_step.json 2>/dev/null; tail -1 $O/${T}_cpu_step.json | cut -c1-300; }
