@@ -217,16 +217,31 @@ __global__ __launch_bounds__(64 * kWaves) void add_ln_bwd(
       }
     }
   }
-  float* out = partials + static_cast<long>(wave) * (2 + L) * cols;
+  // one partial row per WORKGROUP (round 5: a row per wave = 4 096 rows of up to 2 304 floats, 37 MB for the column-sum launch
+  // that follows): the waves add their sums into one LDS row in turn
+  __shared__ float red[(2 + TRANSOAR_TOK_MAX_LEVELS) * cols];
+  const int wv = threadIdx.x >> 6;
+  for (int w = 0; w < kWaves; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int c = i * 128 + 2 * lane;
-    *reinterpret_cast<float2*>(out + c) = float2{dw[2 * i], dw[2 * i + 1]};
-    *reinterpret_cast<float2*>(out + cols + c) = float2{db[2 * i], db[2 * i + 1]};
+      for (int i = 0; i < K; ++i) {
+        const int c = i * 128 + 2 * lane;
+        const float2 z{0.f, 0.f};
+        const float2 a = w ? *reinterpret_cast<const float2*>(red + c) : z, b = w ? *reinterpret_cast<const float2*>(red + cols + c) : z;
+        *reinterpret_cast<float2*>(red + c) = float2{a.x + dw[2 * i], a.y + dw[2 * i + 1]};
+        *reinterpret_cast<float2*>(red + cols + c) = float2{b.x + db[2 * i], b.y + db[2 * i + 1]};
 #pragma unroll
-    for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
-      if (l < L) *reinterpret_cast<float2*>(out + (2 + l) * cols + c) = float2{dle[l][2 * i], dle[l][2 * i + 1]};
+        for (int l = 0; l < TRANSOAR_TOK_MAX_LEVELS; ++l)
+          if (l < L) {
+            const float2 e = w ? *reinterpret_cast<const float2*>(red + (2 + l) * cols + c) : z;
+            *reinterpret_cast<float2*>(red + (2 + l) * cols + c) = float2{e.x + dle[l][2 * i], e.y + dle[l][2 * i + 1]};
+          }
+      }
+    }
+    __syncthreads();
   }
+  float* out = partials + static_cast<long>(blockIdx.x) * (2 + L) * cols;
+  for (int c = threadIdx.x; c < (2 + L) * cols; c += 64 * kWaves) out[c] = red[c];
 }
 
 // Query of the FIRST refine layer: q16 = bf16(x + (pos_sine[s] + level_embed[level(s)])) from the bf16 pyramid tokens
@@ -678,13 +693,17 @@ __global__ __launch_bounds__(256) void ln_rows_bwd(const uint4* __restrict__ g16
 #pragma unroll
     for (int d = G; d < 64; d <<= 1) { dw[i] += __shfl_xor(dw[i], d, 64); db[i] += __shfl_xor(db[i], d, 64); }
   }
+  // ... and the four waves of the workgroup meet in LDS: ONE partial row per workgroup (a row per wave made the column-sum
+  // launch that follows walk 4 096 rows through 24 .. 96 workgroups: 16 us each, 28 of them per Swin step)
+  __shared__ float wg_red[4][2 * 512];
+  const int wv = threadIdx.x >> 6;
   if (sub == 0 && col_on) {
-    float* pr = partials + wave_id * (2L * cols);
-    *reinterpret_cast<float4*>(pr + c0) = float4{dw[0], dw[1], dw[2], dw[3]};
-    *reinterpret_cast<float4*>(pr + c0 + 4) = float4{dw[4], dw[5], dw[6], dw[7]};
-    *reinterpret_cast<float4*>(pr + cols + c0) = float4{db[0], db[1], db[2], db[3]};
-    *reinterpret_cast<float4*>(pr + cols + c0 + 4) = float4{db[4], db[5], db[6], db[7]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { wg_red[wv][c0 + i] = dw[i]; wg_red[wv][cols + c0 + i] = db[i]; }
   }
+  __syncthreads();
+  float* pr = partials + static_cast<long>(blockIdx.x) * (2L * cols);
+  for (int c = threadIdx.x; c < 2 * cols; c += 256) pr[c] = (wg_red[0][c] + wg_red[1][c]) + (wg_red[2][c] + wg_red[3][c]);
 }
 
 // The same two kernels for 512 < cols <= 1536 (the patch-merge norms of the later Swin stages: 8 x 96 = 768 and 8 x 192 = 1536
@@ -800,16 +819,19 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_wide(const uint4* __restrict_
       }
     }
   }
-  float* pr = partials + wave_id * (2L * cols);
+  // one partial row per workgroup (see ln_rows_bwd): the four waves meet in LDS
+  __shared__ float wg_red[4][2 * 512 * kLnWideCh];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int ch = 0; ch < kLnWideCh; ++ch) {
     const int c0 = lane * 8 + 512 * ch;
     if (c0 >= cols) continue;
-    *reinterpret_cast<float4*>(pr + c0) = float4{dw[ch][0], dw[ch][1], dw[ch][2], dw[ch][3]};
-    *reinterpret_cast<float4*>(pr + c0 + 4) = float4{dw[ch][4], dw[ch][5], dw[ch][6], dw[ch][7]};
-    *reinterpret_cast<float4*>(pr + cols + c0) = float4{db[ch][0], db[ch][1], db[ch][2], db[ch][3]};
-    *reinterpret_cast<float4*>(pr + cols + c0 + 4) = float4{db[ch][4], db[ch][5], db[ch][6], db[ch][7]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { wg_red[wv][c0 + i] = dw[ch][i]; wg_red[wv][cols + c0 + i] = db[ch][i]; }
   }
+  __syncthreads();
+  float* pr = partials + static_cast<long>(blockIdx.x) * (2L * cols);
+  for (int c = threadIdx.x; c < 2 * cols; c += 256) pr[c] = (wg_red[0][c] + wg_red[1][c]) + (wg_red[2][c] + wg_red[3][c]);
 }
 
 static unsigned keep_threshold(float keep_prob) {
@@ -1010,7 +1032,7 @@ extern "C" int transoar_ln_rows_forward(const void* x, int x_is_bf16, const floa
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_ln_rows_partial_rows(void) { return kLnBlocks * 4; }
+extern "C" int transoar_ln_rows_partial_rows(void) { return kLnBlocks; }
 
 extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_is_bf16, const float* weight, const float* mean,
                                          const float* rstd, const void* dx_add, void* dx, float* partials, long rows, int cols,
@@ -1033,5 +1055,5 @@ extern "C" int transoar_ln_rows_backward(const void* g16, const void* x, int x_i
 
 extern "C" int transoar_pos_query_partial_rows(void) { return kPersistentWaves / kWaves; }
 
-extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves; }
+extern "C" int transoar_add_layernorm_partial_rows(void) { return kPersistentWaves / kWaves; }
 extern "C" int transoar_tokens_abi_version(void) { return 7; }
