@@ -86,7 +86,15 @@ def main():
     out["update_rel_p90"] = rel[len(rel) // 10][0]
     out["loss_finite"] = bool(torch.isfinite(cap._static_total))
     print(json.dumps(out), flush=True)
-    dist.destroy_process_group()
+    # the result is out: leave without the interpreter's teardown (a process group with captured collectives, its watchdog
+    # thread and two HIP graphs going down together have aborted the process after the fact)
+    try:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    finally:
+        import os
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
