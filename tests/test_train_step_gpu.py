@@ -284,7 +284,7 @@ def test_captured_data_parallel_step():
     env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     # One retry: in two of five full-suite runs the child was ABORTED (SIGABRT out of a c10 / RCCL thread, no Python error);
     # alone or after this file's other tests it has never failed.  A second abort fails the test with both logs.
-    logs = []
+    logs = [("free / total GPU memory before the child", torch.cuda.mem_get_info())]
     for attempt in range(2):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "_dp_capture_probe.py"), str(port + attempt)], cwd=root, env=env,
                            capture_output=True, text=True, timeout=1500)
