@@ -194,6 +194,16 @@ class TrainStep:
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process, or call transoar_amd.use_safe_graph_replay() before the first HIP call")
         if self.capture_optimizer and hasattr(self.optimizer, "prepare_capture"):
             self.optimizer.prepare_capture()
+        if self.reducer.active:
+            # The process group's watchdog thread polls hipEventQuery on the end events of the warm-up steps' collectives
+            # until it has seen them complete (every 100 ms).  Once the capture pulls the group's internal stream into
+            # capture mode, HIP answers such a query with hipErrorCapturedEvent ("event last recorded in a capturing
+            # stream" -- it looks at the stream's state now, not at record time), the watchdog rethrows and the process
+            # aborts: one capture in four died that way when it started within a poll interval of the last eager
+            # collective.  Everything is complete on the GPU (synchronize above); give the watchdog three polls to notice.
+            torch.cuda.synchronize()
+            import time
+            time.sleep(0.3)
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
