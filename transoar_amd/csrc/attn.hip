@@ -567,25 +567,6 @@ template <int HD> struct WinTile {
       *reinterpret_cast<u32x4*>(tile + off(row, half)) = r.a;
     }
   }
-  // one (window, head) slice [n tokens][HD] of a token matrix (tokens `tok_elems` elements apart) -> LDS tile;
-  // rows >= n are zero.  256 threads: thread = (row, half of the row)
-  static __device__ __forceinline__ void load(const unsigned short* __restrict__ src, long tok_elems, int n, unsigned char* tile) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    if constexpr (HD == 32) {
-      u32x4 a{0u, 0u, 0u, 0u}, b{0u, 0u, 0u, 0u};
-      if (row < n) {
-        const u32x4* g = reinterpret_cast<const u32x4*>(src + row * tok_elems + 16 * half);
-        a = g[0];
-        b = g[1];
-      }
-      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half)) = a;
-      *reinterpret_cast<u32x4*>(tile + off(row, 2 * half + 1)) = b;
-    } else {
-      u32x4 a{0u, 0u, 0u, 0u};
-      if (row < n) a = *reinterpret_cast<const u32x4*>(src + row * tok_elems + 8 * half);
-      *reinterpret_cast<u32x4*>(tile + off(row, half)) = a;
-    }
-  }
 };
 // The P / dS tiles [128 rows][128 keys] bf16 keep the 32 8-byte pieces of row i at piece ^ win_p_swz(i) (round 5; they had a
 // 320-byte pitch: rows i and i + 2 of a ds_write_b64 lane group shared their banks, 71 % of the kernel's LDS cycles were
