@@ -16,6 +16,7 @@
 #include "msda3d_brick.hpp"
 #include "msda3d_mma.hpp"
 #include "msda3d_pcm.hpp"
+#include "msda3d_q16.hpp"
 #include "msda3d_tile.hpp"
 #include "msda3d_cells_mma.hpp"
 #include "msda3d_gather.hpp"
@@ -258,6 +259,25 @@ static PcmConst make_pcm_const(const BrickOrder& order) {
   return c;
 }
 
+// Launch constants of msda3d_fwd_q16: the point-column constants + the reciprocals of its unit decode
+static Q16Const make_q16_const(const BrickOrder& order, int M) {
+  Q16Const c;
+  memset(&c, 0, sizeof(c));
+  c.pc = make_pcm_const(order);
+  auto mg = [](long d) -> unsigned long long { return (1ull << 40) / static_cast<unsigned long long>(d > 0 ? d : 1) + 1ull; };
+  c.mg_M = mg(M);
+  c.mg_bricks = mg(order.pad_start[order.L] >> 7);
+  for (int l = 0; l < 4; ++l) {
+    c.mg_nbw[l] = mg(l < order.L ? order.nbw[l] : 1);
+    c.mg_nbh[l] = mg(l < order.L ? order.nbh[l] : 1);
+  }
+  return c;
+}
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 template <typename VT, typename LT>
 static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, void* out, const Dims& d,
@@ -281,6 +301,28 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
     for (int l = 0; small && l < d.L; ++l) small = order.D[l] <= 1000 && order.H[l] <= 1000 && order.W[l] <= 1000;
     // point-column form (msda3d_pcm.hpp): one wave per 8 queries (2x2x2 sub-brick) and head; fp32 locations
     if constexpr (sizeof(LT) == 4) {
+      // 16 queries per wave (msda3d_q16.hpp, round 6): the default of this form
+      if (lg >= 0 && small && pcm_ok(order, d) &&
+          !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA | TRANSOAR_MSDA3D_MMA_Q32 | TRANSOAR_MSDA3D_PCM_Q8))) {
+        ProfScope prof(TRANSOAR_PROF_FWD, st);
+        static const int upw_env = env_int("TRANSOAR_MSDA3D_Q16_UPW", 4), probe = env_int("TRANSOAR_MSDA3D_Q16_PROBE", 0);
+        const unsigned upw = static_cast<unsigned>(upw_env < 1 ? 1 : (upw_env > 64 ? 64 : upw_env));
+        const long n_units = static_cast<long>(d.N) * (order.pad_start[order.L] >> 7) * d.M * 8;
+        const long n_waves = (n_units + upw - 1) / upw;
+        const unsigned vbytes = static_cast<unsigned>(static_cast<long>(d.N) * d.S * d.M * d.C * sizeof(VT));
+        const long n_pts = static_cast<long>(d.N) * d.Lq * d.M * d.L * d.P;
+        const Q16Const* cst = device_const(make_q16_const(order, d.M), st);
+        if (cst == nullptr) return TRANSOAR_ERR_CONST;
+        const dim3 grid(static_cast<unsigned>(((n_waves + 7) / 8) * 8));
+#define TRANSOAR_Q16(PROBE)                                                                                             \
+  hipLaunchKernelGGL((msda3d_fwd_q16<VT, PROBE>), grid, dim3(64), 0, st, v, lo, at, o, d.S, d.M, d.L, vbytes,               \
+                     static_cast<unsigned>(n_pts * 12), static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_units), upw, cst)
+        if (probe == 1) TRANSOAR_Q16(1);
+        else if (probe == 2) TRANSOAR_Q16(2);
+        else TRANSOAR_Q16(0);
+#undef TRANSOAR_Q16
+        return static_cast<int>(hipGetLastError());
+      }
       if (lg >= 0 && small && pcm_ok(order, d) &&
           !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA | TRANSOAR_MSDA3D_MMA_Q32))) {
         ProfScope prof(TRANSOAR_PROF_FWD, st);
