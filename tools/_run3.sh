@@ -1,0 +1,5 @@
+mkdir -p gpurun_out; rm -f gpurun_out/q16_probe.log
+for pb in 2 3; do TRANSOAR_MSDA3D_Q16_PROBE=$pb timeout 200 python tools/check_q16.py --time-only --dists model --iters 20 >> gpurun_out/q16_probe.log 2>&1; done
+grep -v amdgpu.ids gpurun_out/q16_probe.log
+TRANSOAR_MSDA3D_Q16_PROBE=3 bash tools/pmc_any.sh gpurun_out/pmc_q16_p3 q16 -- python tools/check_q16.py --time-only --dists model --iters 5 > gpurun_out/pmc_q16_p3.txt 2>&1
+cat gpurun_out/pmc_q16_p3.txt; rm -rf gpurun_out/pmc_q16_p3

@@ -45,6 +45,8 @@ def _deps(name):
     """Files the library was built from: the depfile of its last build (project files only), or, without
     one, every file of csrc/ and include/."""
     try:
+        if len(LIBS[name]) != 1:
+            raise OSError("no depfile for a library of several sources")
         with open(_dep_path(name)) as f:
             words = f.read().replace("\\\n", " ").split()
         deps = [w for w in words[1:] if not w.startswith("/opt/") and not w.startswith("/usr/")]
@@ -74,6 +76,8 @@ def _compile(name, verbose):
     cmd = [HIPCC] + COMMON_FLAGS + [os.path.join(CSRC, s) for s in LIBS[name]] + ["-o", lib_path(name)]
     if len(LIBS[name]) == 1:
         cmd += ["-MD", "-MF", _dep_path(name)]
+    elif os.path.exists(_dep_path(name)):
+        os.remove(_dep_path(name))       # a depfile from when the library had one source: it misses the newer headers
     if verbose:
         print("[transoar_amd] " + " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -319,6 +319,7 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
                      static_cast<unsigned>(n_pts * 12), static_cast<unsigned>(n_pts * 4), static_cast<unsigned>(n_units), upw, cst)
         if (probe == 1) TRANSOAR_Q16(1);
         else if (probe == 2) TRANSOAR_Q16(2);
+        else if (probe == 3) TRANSOAR_Q16(3);
         else TRANSOAR_Q16(0);
 #undef TRANSOAR_Q16
         return static_cast<int>(hipGetLastError());

@@ -33,8 +33,11 @@
 namespace transoar {
 
 constexpr int kQ16KB = 32;                // value rows per K-block = K-slots of a weight column
-constexpr int kQ16WS = 80;                // bytes per weight column and plane: 32 bf16 K-slots + 16 bytes (16 consecutive columns' 16-byte reads tile the 64 banks)
-constexpr int kQ16Plane = 64 * kQ16WS;    // bytes per plane (64 columns)
+constexpr int kQ16WS = 80;                // bytes per weight column and plane: 32 bf16 K-slots + 16 bytes of padding (the 16-byte reads of 16 consecutive
+                                          // columns tile the 64 banks).  The padding is also the guard of the pair stores: K-slot 32 of a column is its
+                                          // first padding slot, K-slot -1 the last padding slot of the column before it (of the 16 bytes in front of column 0)
+constexpr int kQ16W0 = 16;                // byte offset of column 0 inside a plane
+constexpr int kQ16Plane = 64 * kQ16WS + 16;    // bytes per plane (64 columns)
 constexpr int kQ16BoxRows = 256;          // larger boxes: explicit (column, corner) slots, 512 per level
 constexpr int kQ16Far = 0x20000000;       // K-slot of a skipped point: in no block
 constexpr unsigned kQ16Oob = 0xffffff00u; // byte offset past every buffer, still past it with a small immediate added
@@ -143,8 +146,8 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
   const int st_row = lane >> 3, st_vec = lane & 7;
   const int st_swz = (st_vec ^ ((st_row & 2) << 1)) * 16;
   const int tr_off0 = ((16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2) ^ ((((lane & 15) >> 2) & 2) << 5), tr_off1 = tr_off0 ^ 64;
-  unsigned char* const wcol = wbuf + lane * WS;                                   // this lane's weight column (hi plane)
-  const unsigned char* const wrd = wbuf + n * WS + kh * 16;                       // its A-fragment reads: column n (+32), K-slots 8 kh ..
+  unsigned char* const wcol = wbuf + kQ16W0 + lane * WS - 2;                      // K-slot -1 of this lane's weight column (hi plane)
+  const unsigned char* const wrd = wbuf + kQ16W0 + n * WS + kh * 16;              // its A-fragment reads: column n (+32), K-slots 8 kh ..
 
   Q16Unit un = decode(u);
   int s = query_row(un, dq, hq, wq);
@@ -232,12 +235,6 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
     // ---- the next unit's parameters: requested now, used after this unit's rows
     const unsigned u_nx = u + 1u;
     const bool more = u_nx < u_end;
-    if (more) {
-      if constexpr (PROBE == 0) {
-        const Q16Unit un_nx = decode(u_nx);
-        pr = issue_params(un_nx, query_row(un_nx, dq, hq, wq));
-      }
-    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -289,29 +286,35 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
     int row_off = 0;
     static_for<0, kPcmLevels>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
+      // the next unit's parameters are requested when the last level begins: by then the registers of the earlier
+      // levels' geometry are free, and the words have this level's blocks and the output pass to arrive in
+      if (l + 1 == L && more) {
+        if constexpr (PROBE == 0) {
+          const Q16Unit un_nx = decode(u_nx);
+          pr = issue_params(un_nx, query_row(un_nx, dq, hq, wq));
+        }
+      }
       if (mode[l] == 0) return;
       const PcmBox bx = box[l];
       const int THW = bx.TH * bx.TW;
       const int R = mode[l] == 1 ? bx.TD * THW : 512;
-      // ---- the lane's eight entries on this level: first K-slot and the (wave-uniform) slot offsets of the corners
-      int c0, soff[8];
+      // ---- the lane's eight entries on this level: four (dw = 0, dw = 1) pairs in adjacent K-slots.  c1 = first
+      // K-slot + 1, sp[j] the (wave-uniform) slot offset of pair j = 2 dd + dh.  A pair is written when either slot is in the
+      // block; the other one then lands in a guard slot of the column (K-slot -1 or 32), which is never read.
+      // A corner whose fraction is zero does not widen the box (t0 above); its slot may lie outside the box and alias
+      // another slot of the column.  Such a ghost never destroys a real weight: slot offsets grow with the corner
+      // number (TH*TW >= TW >= 1) and the entries are written in corner order, so a real entry that shares a ghost's slot
+      // is always written after it.
+      int c1, sp[4];
       if (mode[l] == 1) {
         const int pd = dhw[l];
         const int d1 = pd & 1023, h1 = (pd >> 10) & 1023, w1 = pd >> 20;        // d0 + 1, h0 + 1, w0 + 1
-        const int base = __mul24(__mul24(bx.bd + 1, bx.TH) + (bx.bh + 1), bx.TW) + (bx.bw + 1);
-        c0 = pd == kPcmSkip ? kQ16Far : __mul24(__mul24(d1, bx.TH) + h1, bx.TW) + w1 - base;
-        // A corner whose fraction is zero has weight zero and does not widen the box (see t0 above): its slot may lie
-        // outside the box and then aliases another slot of the column.  It can alias one that holds a real weight only
-        // if two of the offsets 1, TW, TH*TW coincide, i.e. TW == 1 or TH == 1 -- and then EVERY point of the wave has
-        // that fraction zero: the whole corner class is dropped, wave-uniformly.  (Any other zero lands on a slot its
-        // column does not use, or outside the block.)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          soff[e] = (((e & 1) && bx.TW == 1) || ((e & 2) && bx.TH == 1)) ? kQ16Far : ((e >> 2) & 1) * THW + ((e >> 1) & 1) * bx.TW + (e & 1);
+        const int base = __mul24(__mul24(bx.bd + 1, bx.TH) + (bx.bh + 1), bx.TW) + (bx.bw + 1) - 1;
+        c1 = pd == kPcmSkip ? kQ16Far : __mul24(__mul24(d1, bx.TH) + h1, bx.TW) + w1 - base;
+        sp[0] = 0; sp[1] = bx.TW; sp[2] = THW; sp[3] = THW + bx.TW;
       } else {
-        c0 = dhw[l] == kPcmSkip ? kQ16Far : lane * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) soff[e] = e;
+        c1 = dhw[l] == kPcmSkip ? kQ16Far : lane * 8 + 1;
+        sp[0] = 0; sp[1] = 2; sp[2] = 4; sp[3] = 6;
       }
       unsigned wq8[8];
       {
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
       for (int hb = 0; hb < nb; ++hb) {
         const int half = hb & 1;                                            // which half of the 64 row offsets in row_off
         const int k0 = hb * KB;
-        const int nch = (min(KB, R - k0) + 15) >> 4;                        // 16-row chunks of this block: 1 or 2
+        const int nch = PROBE == 3 ? 2 : (min(KB, R - k0) + 15) >> 4;        // 16-row chunks of this block: 1 or 2
         // ---- staged rows -> LDS
 #pragma unroll
         for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_swz) = pre[it];
@@ -336,15 +339,21 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
 #pragma unroll
           for (int it = 2; it < 4; ++it) *reinterpret_cast<u32x4*>(vbuf + (it * 8 + st_row) * VP + st_swz) = pre[it];
         }
-        // ---- the lane's entries that fall into this block
-        int wad[8];
+        // ---- the lane's pairs that touch this block: t1 = (K-slot of the pair's first entry) - k0 + 1 in [0, 32]
+        int t1[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const unsigned t = static_cast<unsigned>(c0 + (soff[e] - k0));
-          wad[e] = static_cast<int>(t) * 2;
-          if (t < static_cast<unsigned>(KB)) {
-            *reinterpret_cast<unsigned short*>(wcol + wad[e]) = static_cast<unsigned short>(wq8[e] >> 16);
-            *reinterpret_cast<unsigned short*>(wcol + kQ16Plane + wad[e]) = static_cast<unsigned short>(wq8[e]);
+        for (int j = 0; j < 4; ++j) {
+          t1[j] = c1 + (sp[j] - k0);
+          if (PROBE != 3 && static_cast<unsigned>(t1[j]) < static_cast<unsigned>(KB + 1)) {
+            // (two 16-bit stores per plane on purpose: hipcc would merge adjacent ones into a 32-bit store at a 2-byte
+            // aligned address, which the LDS executes -- correctly -- at less than half the rate)
+            unsigned char* a = wcol + 2 * t1[j];
+            unsigned char* a2 = a;
+            asm volatile("" : "+v"(a2));
+            *reinterpret_cast<unsigned short*>(a) = static_cast<unsigned short>(wq8[2 * j] >> 16);
+            *reinterpret_cast<unsigned short*>(a2 + 2) = static_cast<unsigned short>(wq8[2 * j + 1] >> 16);
+            *reinterpret_cast<unsigned short*>(a + kQ16Plane) = static_cast<unsigned short>(wq8[2 * j]);
+            *reinterpret_cast<unsigned short*>(a2 + kQ16Plane + 2) = static_cast<unsigned short>(wq8[2 * j + 1]);
           }
         }
         // ---- prefetch the next block (of this level, or the first of the next one)
@@ -360,38 +369,51 @@ __global__ __launch_bounds__(64, 2) void msda3d_fwd_q16(
             have_pre = true;
           }
         }
-        // ---- 16-row chunks on the matrix cores; an explicit block holds the slots of 4 columns of ONE group
-        const int only = mode[l] == 2 ? (hb >> 3) : -1;
-        for (int kc = 0; kc < nch; ++kc) {
-          const unsigned char* vrow = vbuf + (kc * 16 + 8 * kh + ((lane & 15) >> 2)) * VP;
-          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-          const s16x4 b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + tr_off0));
-          const s16x4 b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * VP + tr_off0));
-          const s16x4 b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + tr_off1));
-          const s16x4 b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * VP + tr_off1));
-          const s16x8 v0 = __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7);
-          const s16x8 v1 = __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7);
+        // ---- 16-row chunks on the matrix cores (B = V: lane supplies row (lane & 15) >> 2 of its group's 4-row set, 4 channels;
+        // receives its channel's column).  The second chunk's fragment reads follow the first chunk's MFMAs into the queue.
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const unsigned char* vrow = vbuf + (8 * kh + ((lane & 15) >> 2)) * VP;
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            if (only >= 0 && only != g) continue;
-            const unsigned char* wp = wrd + g * 32 * WS + kc * 32;
-            const s16x8 whi = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wp));
-            const s16x8 wlo = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wp + kQ16Plane));
-            acc[g][0] = Mma<VT>::mfma(whi, v0, acc[g][0]);
-            acc[g][1] = Mma<VT>::mfma(whi, v1, acc[g][1]);
-            acc[g][0] = Mma<VT>::mfma(wlo, v0, acc[g][0]);
-            acc[g][1] = Mma<VT>::mfma(wlo, v1, acc[g][1]);
+        for (int kc = 0; kc < 2; ++kc) {
+          if (kc < nch) {
+            const unsigned char* vr = vrow + kc * 16 * VP;
+            const s16x4 b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + tr_off0));
+            const s16x4 b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + 4 * VP + tr_off0));
+            const s16x4 b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + tr_off1));
+            const s16x4 b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + 4 * VP + tr_off1));
+            const s16x8 v0 = __builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7);
+            const s16x8 v1 = __builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7);
+            s16x8 whi[2], wlo[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const unsigned char* wp = wrd + g * 32 * WS + kc * 32;
+              whi[g] = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wp));
+              wlo[g] = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wp + kQ16Plane));
+            }
+            acc[0][0] = Mma<VT>::mfma(whi[0], v0, acc[0][0]);
+            acc[0][1] = Mma<VT>::mfma(whi[0], v1, acc[0][1]);
+            acc[1][0] = Mma<VT>::mfma(whi[1], v0, acc[1][0]);
+            acc[1][1] = Mma<VT>::mfma(whi[1], v1, acc[1][1]);
+            acc[0][0] = Mma<VT>::mfma(wlo[0], v0, acc[0][0]);
+            acc[0][1] = Mma<VT>::mfma(wlo[0], v1, acc[0][1]);
+            acc[1][0] = Mma<VT>::mfma(wlo[1], v0, acc[1][0]);
+            acc[1][1] = Mma<VT>::mfma(wlo[1], v1, acc[1][1]);
           }
         }
-        // ---- clear the block's entries again (the test is made again from the address: eight lane masks kept across
-        // the matrix work would be spilled)
+        // ---- clear the block's pairs again (the test is made again from t1: lane masks kept across the matrix work
+        // would cost scalar registers the kernel does not have)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          int a = wad[e];
-          asm volatile("" : "+v"(a));
-          if (static_cast<unsigned>(a) < 2u * KB) {
-            *reinterpret_cast<unsigned short*>(wcol + a) = 0;
-            *reinterpret_cast<unsigned short*>(wcol + kQ16Plane + a) = 0;
+        for (int j = 0; j < 4; ++j) {
+          int t = t1[j];
+          asm volatile("" : "+v"(t));
+          if (PROBE != 3 && static_cast<unsigned>(t) < static_cast<unsigned>(KB + 1)) {
+            unsigned char* a = wcol + 2 * t;
+            unsigned char* a2 = a;
+            asm volatile("" : "+v"(a2));
+            *reinterpret_cast<unsigned short*>(a) = 0;
+            *reinterpret_cast<unsigned short*>(a2 + 2) = 0;
+            *reinterpret_cast<unsigned short*>(a + kQ16Plane) = 0;
+            *reinterpret_cast<unsigned short*>(a2 + kQ16Plane + 2) = 0;
           }
         }
       }
