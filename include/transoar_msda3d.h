@@ -77,7 +77,8 @@ enum {
 #define TRANSOAR_MSDA3D_FORK 8u             /* backward: run the coarse-level grad_value walk on an internal side stream */
 #define TRANSOAR_MSDA3D_NO_MMA 16u            /* forward: LDS-tiled per-corner kernel instead of the matrix-core gather */
 #define TRANSOAR_MSDA3D_MMA_Q32 32u           /* forward: round 2's matrix-core gather (32 queries per wave, fp32 weight block) instead of the point-column one */
-#define TRANSOAR_MSDA3D_PCM_Q8 128u            /* forward: round 3's point-column gather (8 queries per wave) instead of round 6's (16 queries per wave, msda3d_q16.hpp) */
+#define TRANSOAR_MSDA3D_Q16 128u               /* forward: round 6's 16-queries-per-wave point-column gather (msda3d_q16.hpp) instead of round 3's (8 per wave).
+                                                * Same results; slower as measured -- the probe of that carving, not the default. */
 #define TRANSOAR_MSDA3D_DETERMINISTIC 64u      /* backward: bit-stable grad_value.  The sampling points are ordered by (cell, canonical
                                                 * point index) with a stable radix sort instead of by the arrival order of atomic
                                                 * cursors, and every level is accumulated by the brick-owner walk (no fp32 row atomics).

@@ -19,6 +19,7 @@ no fixed seed; G1 is that test's "Small" shape with seeds fixed, G3 its
     python tests/golden/make_golden.py --swin     # only g8 (Swin encoder backbone)
     python tests/golden/make_golden.py --swin-stage   # only g9 (one full-width Swin stage: head dimension 32)
     python tests/golden/make_golden.py --flagship     # only g10 (full-width flagship eval forward, one volume; minutes)
+    python tests/golden/make_golden.py --flagship-grad   # only g11 (full-width flagship loss gradients, one volume)
 
 g6/g7 import the reference's full model, which needs two container-only shims
 (a stub ``timm.models.layers`` and ``Tensor.cuda = identity``).
@@ -331,6 +332,49 @@ def g10_flagship_forward():
 G10_GAIN = 1.0
 
 
+def g11_flagship_gradients():
+    """The full-width flagship again (as g10), now one TRAINING-loss backward of the reference on its use_cuda=False fp32
+    path in eval mode (no dropout noise): weighted loss of the reference's criterion on one analytic volume with the
+    synthetic targets of the bench, gradients of every parameter.  Stored: the loss values, and per parameter the sum, the
+    abs-sum and 16 entries at fixed positions (round-5 VERDICT item 8b: the whole-model gradient was only bounded
+    statistically).  ~40 GB and a quarter of an hour of CPU time here; the fixture is ~60 KB."""
+    _reference_model_imports()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests._inputs import analytic_volume, fill_deterministic
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar.models.transoarnet import TransoarNet
+    from transoar.models.build import build_criterion
+    cfg = visceral_config(refine=True, use_cuda=False)
+    cfg["bbox_properties"] = synthetic_bbox_properties(20, seed=0)
+    torch.manual_seed(0)
+    net = TransoarNet(cfg).eval()
+    fill_deterministic(net, gain=G10_GAIN)
+    crit = build_criterion(cfg)
+    x = analytic_volume((160, 160, 256), batch=1)
+    out = net(x)
+    targets = synthetic_targets(1, 20, seed=1)
+    losses = crit(out, targets, None, net._anchors)
+    coefs = cfg["loss_coefs"]
+    total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
+    params = dict(net.named_parameters())
+    grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    store = {"gain": np.float64(G10_GAIN), "total": np.float64(float(total)),
+             "loss_names": np.array(list(losses.keys())), "loss_values": np.array([float(v) for v in losses.values()]),
+             "grad_names": np.array(list(params.keys())), "grad_is_none": np.array([g is None for g in grads]),
+             "grad_sums": np.array([0.0 if g is None else g.double().sum().item() for g in grads]),
+             "grad_abs_sums": np.array([0.0 if g is None else g.double().abs().sum().item() for g in grads]),
+             "grad_max": np.array([0.0 if g is None else g.abs().max().item() for g in grads])}
+    samples = np.zeros((len(grads), 16), np.float32)
+    for i, g in enumerate(grads):
+        if g is not None:
+            flat = g.reshape(-1)
+            idx = (torch.arange(16, dtype=torch.long) * 2654435761 + 12345 * i) % flat.numel()      # fixed, spread positions
+            samples[i] = flat[idx].numpy()
+    store["grad_samples"] = samples
+    np.savez_compressed(os.path.join(HERE, "g11_flagship_gradients.npz"), **store)
+    print("g11: total", float(total), "largest |grad|", float(store["grad_max"].max()))
+
+
 def g8_swin_backbone():
     """AttnFPN with use_encoder_attn=True (Swin stages 2-5; BASELINE config #4 at reduced width) on a 32x32x64
     volume: window / shifted-window blocks with padding (16x16x32, 8x8x16 grids), a mixed case (4x4x8: one
@@ -399,6 +443,9 @@ if __name__ == "__main__" and "--swin" in sys.argv:
     g8_swin_backbone()
     sys.exit(0)
 
+if __name__ == "__main__" and "--flagship-grad" in sys.argv:
+    g11_flagship_gradients()
+    sys.exit(0)
 if __name__ == "__main__" and "--flagship" in sys.argv:
     g10_flagship_forward()
     sys.exit(0)

@@ -130,8 +130,9 @@ def test_g6_backbone(golden_dir, debug_core, device, tag, refine):
     for name, g, s, a in zip(params, grads, z[tag + ".grad_sums"], z[tag + ".grad_abs_sums"]):
         got = 0.0 if g is None else g.double().sum().item()
         # checksums of fp32 gradients through 12 InstanceNorm layers are ill-conditioned (see
-        # tests/test_data_parallel.py): 2e-4 of sum|g| CPU-vs-CPU, 5e-3 CPU golden vs GPU kernels
-        tol = 2e-4 if device == "cpu" else 5e-3
+        # tests/test_data_parallel.py): CPU-vs-CPU they move with the thread count torch's convolution blocks for
+        # (1.2e-4 at 8 threads, 3.2e-4 at 4 -- whatever an earlier test of the session left set): 6e-4; 5e-3 CPU golden vs GPU kernels
+        tol = 6e-4 if device == "cpu" else 5e-3
         assert abs(got - s) <= tol * max(a, 1e-6) + 1e-7, (name, got, float(s), float(a))
 
 

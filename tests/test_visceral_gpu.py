@@ -86,3 +86,93 @@ def test_g10_flagship_forward_against_the_reference(golden_dir):
 # (profiles/r05_observed_errors.json)
 G10_FP32_LOGITS, G10_FP32_BOXES = 1e-4, 1e-4
 G10_BF16_LOGITS, G10_BF16_BOXES = 1e-2, 4e-4
+
+
+def _g11_errors(net, z, x, targets, crit, cfg, autocast):
+    """-> (loss errors, per-parameter max-normalised error of the 16 stored entries, of the checksum) of one loss backward."""
+    import numpy as np
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        out = net(x)
+        losses = crit(out, targets, None, net._anchors)
+        coefs = cfg["loss_coefs"]
+        total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
+    params = dict(net.named_parameters())
+    assert list(params.keys()) == list(z["grad_names"])
+    grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    assert [g is None for g in grads] == list(z["grad_is_none"])
+    loss_err = max(abs(float(v) - ref) / max(abs(ref), 1e-3) for (k, v), ref in zip(losses.items(), z["loss_values"]))
+    per = []
+    for i, (name, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        flat = g.detach().float().reshape(-1).cpu()
+        idx = (torch.arange(16, dtype=torch.long) * 2654435761 + 12345 * i) % flat.numel()
+        mx = max(float(z["grad_max"][i]), 1e-30)
+        e_s = float((flat[idx] - torch.from_numpy(z["grad_samples"][i])).abs().max()) / mx
+        e_c = abs(float(flat.double().sum()) - float(z["grad_sums"][i])) / max(float(z["grad_abs_sums"][i]), 1e-30)
+        per.append((e_s, e_c, name))
+    return loss_err, abs(float(total) - float(z["total"])) / abs(float(z["total"])), per
+
+
+def test_g11_flagship_gradients_against_the_reference(golden_dir):
+    """Golden g11: one training-loss backward of the reference's full-width TransoarNet (refine on) on its use_cuda=False
+    fp32 path, eval mode, one analytic volume + the bench's synthetic targets (tests/golden/make_golden.py
+    --flagship-grad).  Per parameter the fixture holds 16 entries of the gradient, its sum and abs-sum: ours in fp32 through
+    the per-item kernels and under bf16 autocast through every kernel the bench runs (round-5 VERDICT item 8b: the
+    whole-model gradient was only bounded statistically, and g10 pinned the forward alone).  Errors are normalised by the
+    tensor's own maximum (samples) / abs-sum (checksum)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import numpy as np
+    from tests._inputs import analytic_volume, fill_deterministic
+    from tests._observe import observe
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+    z = np.load(os.path.join(golden_dir, "g11_flagship_gradients.npz"))
+    cfg = visceral_config(refine=True, use_cuda=True)
+    cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+    torch.manual_seed(0)
+    net = TransoarNet(cfg).eval()
+    fill_deterministic(net, gain=float(z["gain"]))
+    net = net.cuda()
+    crit = build_criterion(cfg)
+    x = analytic_volume((160, 160, 256), batch=1).cuda()
+    targets = synthetic_targets(1, 20, seed=1, device="cuda")
+    gmax = {n: float(m) for n, m in zip(z["grad_names"], z["grad_max"])}
+    for tag, autocast, tol in (("fp32", False, G11_FP32), ("bf16", True, G11_BF16)):
+        loss_err, total_err, per = _g11_errors(net, z, x, targets, crit, cfg, autocast)
+        # tensors the loss really depends on (reference max |g| > 1e-4: the neck, the heads, the refine block, the FPN decoder,
+        # 83 of 154) and the rest (the encoder: max |g| 1e-5 ... 1e-7 in this fixture -- behind its 12 InstanceNorms such a
+        # gradient is fp32 rounding noise of order itself, in the reference's own evaluation as much as in ours)
+        main = [(s_, c_, n) for s_, c_, n in per if gmax[n] > 1e-4]
+        rest = [(s_, c_, n) for s_, c_, n in per if gmax[n] <= 1e-4]
+        assert len(main) >= 80, len(main)
+        worst_s, worst_c = max(main), max((c_, s_, n) for s_, c_, n in main)
+        med_s = sorted(s_ for s_, _, _ in main)[len(main) // 2]
+        rest_s = max(rest)
+        observe("g11.%s.loss" % tag, max(loss_err, total_err), tol["loss"])
+        observe("g11.%s.grad_samples.max_norm" % tag, worst_s[0], tol["samples"])
+        observe("g11.%s.grad_samples.median" % tag, med_s, tol["median"])
+        observe("g11.%s.grad_checksum" % tag, worst_c[0], tol["checksum"])
+        if tol["rest"] is not None:
+            observe("g11.%s.grad_samples.tiny_tensors" % tag, rest_s[0], tol["rest"])
+        if os.environ.get("TRANSOAR_G11_DUMP"):
+            import json
+            with open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "g11_%s.json" % tag), "w") as fh:
+                json.dump([(n, s_, c_, gmax[n]) for s_, c_, n in per], fh)
+        print("g11", tag, "loss %.3g total %.3g; samples worst %.3g (%s) median %.3g; checksum worst %.3g (%s); tiny tensors %.3g (%s)"
+              % (loss_err, total_err, worst_s[0], worst_s[2], med_s, worst_c[0], worst_c[2], rest_s[0], rest_s[2]))
+        assert max(loss_err, total_err) <= tol["loss"], (tag, loss_err, total_err)
+        assert worst_s[0] <= tol["samples"], (tag, sorted(main, reverse=True)[:5])
+        assert med_s <= tol["median"], (tag, med_s)
+        assert worst_c[0] <= tol["checksum"], (tag, worst_c)
+        assert tol["rest"] is None or rest_s[0] <= tol["rest"], (tag, rest_s)
+
+
+# fp32: north_star's 1e-4 on the tensors the loss depends on (observed: loss 1.5e-7, samples 6.0e-6, checksum 7.5e-7); the tiny
+# encoder gradients at 2x the observed 0.79.  bf16: 2x observed (loss 0.026; samples 0.27 worst -- bias / norm gradients of the
+# refine block: sums over 117 000 tokens of bf16-rounded terms that cancel -- median 0.011; checksum 0.047); the tiny tensors
+# are not bounded under bf16 (observed 9: noise on noise).  profiles/r06_observed_errors.json
+G11_FP32 = {"loss": 1e-4, "samples": 1e-4, "median": 1e-5, "checksum": 1e-4, "rest": 1.6}
+G11_BF16 = {"loss": 5.5e-2, "samples": 0.55, "median": 2.5e-2, "checksum": 0.1, "rest": None}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 6's forward gather (msda3d_q16.hpp, 16 queries per wave) against round 3's point-column kernel (flag 128) and the
+"""Round 6's forward gather (msda3d_q16.hpp, 16 queries per wave) (flag 128) against round 3's point-column kernel (the default) and the
 per-corner brick kernel (flag 16) on the flagship pyramid: differences and times per location distribution.
 
     python tools/check_q16.py [--geometry visceral|amos] [--n 2] [--iters 20] [--dists model,init,uniform,wide] [--time-only]
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import _inputs  # noqa: E402
 from transoar_amd import MSDA  # noqa: E402
 
-PCM_Q8, NO_MMA = 128, 16
+Q16, NO_MMA = 128, 16
 
 
 def timed(fn, iters):
@@ -56,7 +56,7 @@ def main():
         if dist == "wide":
             loc = (loc - 0.5) * 1.3 + 0.5 + 0.05 * torch.randn_like(loc)
         v = value.to(vdt)
-        kernels = (("q16", 0),) if args.time_only else (("q16", 0), ("pcm", PCM_Q8), ("brick", NO_MMA))
+        kernels = (("q16", Q16),) if args.time_only else (("q16", Q16), ("pcm", 0), ("brick", NO_MMA))
         out = {}
         for name, fl in kernels:
             MSDA.flags = fl

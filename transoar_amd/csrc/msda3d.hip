@@ -301,9 +301,10 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
     for (int l = 0; small && l < d.L; ++l) small = order.D[l] <= 1000 && order.H[l] <= 1000 && order.W[l] <= 1000;
     // point-column form (msda3d_pcm.hpp): one wave per 8 queries (2x2x2 sub-brick) and head; fp32 locations
     if constexpr (sizeof(LT) == 4) {
-      // 16 queries per wave (msda3d_q16.hpp, round 6): the default of this form
-      if (lg >= 0 && small && pcm_ok(order, d) &&
-          !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA | TRANSOAR_MSDA3D_MMA_Q32 | TRANSOAR_MSDA3D_PCM_Q8))) {
+      // 16 queries per wave (msda3d_q16.hpp, round 6): measured SLOWER than the 8-query kernel below;
+      // kept behind its flag as the carving's speed-of-light probe, parity-tested
+      if (lg >= 0 && small && pcm_ok(order, d) && (flags & TRANSOAR_MSDA3D_Q16) &&
+          !(flags & (TRANSOAR_MSDA3D_NO_BRICK | TRANSOAR_MSDA3D_NO_MMA | TRANSOAR_MSDA3D_MMA_Q32))) {
         ProfScope prof(TRANSOAR_PROF_FWD, st);
         static const int upw_env = env_int("TRANSOAR_MSDA3D_Q16_UPW", 4), probe = env_int("TRANSOAR_MSDA3D_Q16_PROBE", 0);
         const unsigned upw = static_cast<unsigned>(upw_env < 1 ? 1 : (upw_env > 64 ? 64 : upw_env));

@@ -109,6 +109,14 @@ class GradientAllReducer:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
         return counts
 
+    def reduce_counts_async(self, counts):
+        """The same sum, launched without waiting: returns a handle whose wait() must precede the first use of `counts`
+        (None for one rank).  The eager step opens with it and waits only in front of the criterion, so that no blocking
+        collective stands between two steps (on RCCL the wait is a stream dependency, not a host wait)."""
+        if self.active:
+            return dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
     def begin(self):
         """Call before forward/backward: drop the old gradients (autograd allocates fresh ones; a bucket is packed when
         its last gradient has landed)."""
@@ -129,10 +137,14 @@ class GradientAllReducer:
             for p, v in live:
                 p.grad = v
         # a parameter of the bucket without a gradient this step contributes ZERO to the exchange, not last step's slice
-        # (first step: every parameter that has not fired; later: a live parameter whose branch was skipped on this rank)
+        # (first step: every parameter that has not fired; later: a live parameter whose branch was skipped on this rank).
+        # Its .grad becomes the view all the same: after the exchange it holds the other ranks' sum, and every rank must
+        # step the same parameter set or the replicas drift apart (a parameter that no rank ever trains is reset to None by
+        # _end_first_step)
         for p, v in zip(b.params, b.views):
             if p.grad is None and p not in self._dead:
                 v.zero_()
+                p.grad = v
 
     def _on_grad(self, p):
         b = self._bucket_of[p]

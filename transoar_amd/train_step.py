@@ -114,10 +114,13 @@ class TrainStep:
             targets = DenseTargets.from_list(targets, self.num_classes, data.device)
         if counts is not None:
             targets = DenseTargets(targets.boxes, targets.present, counts[0], counts[1])
-        elif self.reducer.active:
+        pending = None
+        if counts is None and self.reducer.active:
+            # the rank-summed normalisers are only needed by the criterion: the sum is launched here and waited for after
+            # the model's forward (no blocking collective opens a step)
             counts = torch.stack((torch.as_tensor(float(targets.num_boxes), device=data.device),
                                   targets.present.sum().float()))
-            counts = self.reducer.reduce_counts(counts)
+            pending = self.reducer.reduce_counts_async(counts)
             targets = DenseTargets(targets.boxes, targets.present, counts[0], counts[1])
         enabled = self.amp_dtype is not None and self.amp_dtype != torch.float32
         mirrors = None
@@ -128,6 +131,8 @@ class TrainStep:
         with shadow.fresh(mirrors), \
                 torch.autocast(self.device_type, dtype=self.amp_dtype if enabled else torch.bfloat16, enabled=enabled):
             out = self.model(data)
+            if pending is not None:
+                pending.wait()
             losses = self.criterion(out, targets, seg_targets, self.model._anchors)
             coefs = self.config["loss_coefs"]
             total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
@@ -201,9 +206,12 @@ class TrainStep:
             # stream" -- it looks at the stream's state now, not at record time), the watchdog rethrows and the process
             # aborts: one capture in four died that way when it started within a poll interval of the last eager
             # collective.  Everything is complete on the GPU (synchronize above); give the watchdog three polls to notice.
+            # (ProcessGroupNCCL exposes neither its work queue nor a flush of it to Python, and the poll interval is a
+            # compile-time constant of torch: the wait is a multiple of it, TRANSOAR_DP_CAPTURE_SETTLE_MS to change it --
+            # e.g. on a host so loaded that the watchdog thread is starved for longer.)
             torch.cuda.synchronize()
             import time
-            time.sleep(0.3)
+            time.sleep(max(0.0, float(os.environ.get("TRANSOAR_DP_CAPTURE_SETTLE_MS", "300")) * 1e-3))
         graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while we capture: only calls made
         # by THIS thread may invalidate the capture
