@@ -384,6 +384,25 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     trace("timed region done")
+    # what the host needs to enqueue ONE step into an EMPTY queue (host_enqueue_ms_per_step above is taken with the GPU running
+    # behind: once the queue is full it measures back-pressure, i.e. the step time again).  The mode that was timed here; the eager
+    # step (the data-parallel default, one process per GPU: what 8 ranks on one host contend with) below, among the eager
+    # profile steps.  (A captured whole-step graph must not be replayed again after EAGER optimizer steps of the same TrainStep:
+    # measured to fault, tools/replay_after_eager.py, DESIGN section 12 -- hence the order.)
+    def drained(n=4):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            step(x, targets)
+            ts.append(time.perf_counter() - h0)
+        torch.cuda.synchronize()
+        return round(sorted(ts[1:])[(n - 1) // 2] * 1e3, 2)
+    prof = None
+    if step._graph is None:                    # eager: the library's event pairs of the timed steps, before anything else runs
+        _native.profile_enable(False)
+        prof = _native.profile_read()
+    host_drained = {"timed_mode": drained()}
     # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the
     # launch stream.  A replayed graph re-records nothing, so in graph mode they come from eager steps of
     # the same model state run right after the timed replays (kernel durations do not depend on how the
@@ -399,32 +418,14 @@ def main():
             step(x, targets)
             trace("eager profile step %d" % i)
         torch.cuda.synchronize()
+        _native.profile_enable(False)
+        prof = _native.profile_read()
+        host_drained["eager"] = drained()
         step._graph = graph
-    _native.profile_enable(False)
-    prof = _native.profile_read()
-    # what the host needs to enqueue ONE step into an EMPTY queue (the figure above is taken with the GPU running behind: once
-    # the queue is full it measures back-pressure, i.e. the step time again): the mode that was timed, and the eager step
-    # (the data-parallel default, one process per GPU: its host time per rank is what 8 ranks on one host contend with)
-    host_drained = {}
-    for mode_name, use_graph in (("timed_mode", True), ("eager", False)):
-        graph = step._graph
-        if not use_graph:
-            if graph is None:
-                host_drained[mode_name] = host_drained.get("timed_mode")
-                continue
-            step._graph = None
-            step.reducer.overlap = True
-        ts = []
-        for i in range(4):
-            torch.cuda.synchronize()
-            h0 = time.perf_counter()
-            step(x, targets)
-            ts.append(time.perf_counter() - h0)
-        torch.cuda.synchronize()
-        step._graph = graph
-        host_drained[mode_name] = round(sorted(ts[1:])[1] * 1e3, 2)
+    else:
+        host_drained["eager"] = host_drained["timed_mode"]
     other_states = None
-    if rank == 0 and not args.no_refine and not args.fp32 and not args.swin:
+    if rank == 0 and not args.no_refine and not args.fp32 and not args.swin and not os.environ.get("TRANSOAR_BENCH_SKIP_OTHER"):
         try:
             other_states = gather_other_states(dev, args.batch)
         except Exception as e:          # report, never fake
