@@ -220,6 +220,15 @@ def test_captured_adamw_step_follows_eager_adamw_steps():
             rel2.append(float(((a.detach() - s) - (b.detach() - s)).norm()) / den)
     rel2.sort()
     assert rel2[len(rel2) // 2] <= 0.3, rel2[len(rel2) // 2]      # third step: the two trajectories have drifted by their rounding; garbage is >= 1
+    # ---- an eager optimizer step behind the graph's back (what bench.py does for its profile steps) must not be followed by
+    # a replay: that faults on the GPU (tools/replay_after_eager.py) -- TrainStep refuses instead
+    graph, cap._graph = cap._graph, None
+    cap(xb, tb)
+    cap._graph = graph
+    with pytest.raises(RuntimeError, match="EAGER optimizer step"):
+        cap(xb, tb)
+    cap.drop_graph()
+    cap(xb, tb)                          # eager again: fine
 
 
 @pytest.mark.gpu

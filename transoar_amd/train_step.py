@@ -63,6 +63,8 @@ class TrainStep:
         # gradient tensor (no zero-fill of buckets, no per-parameter accumulate kernel: ~170 launches less per step)
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=False)
         self._graph = None
+        self._stale_graph = False          # an eager optimizer step ran after a capture that holds the AdamW update
+        self._captured_with_optimizer = False
         self._replay_done = None
         self._static_counts = None
         self._static_counts_local = None
@@ -246,6 +248,7 @@ class TrainStep:
             raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
         self._expect_total = None
         self._graph = graph
+        self._captured_with_optimizer, self._stale_graph = bool(self.capture_optimizer), False
         # TRANSOAR_GRAPH_SERIALIZE=1: never launch the graph again before its previous launch has finished on the GPU
         self._replay_done = torch.cuda.Event() if os.environ.get("TRANSOAR_GRAPH_SERIALIZE") else None
         return self
@@ -303,6 +306,10 @@ class TrainStep:
         return total.detach(), losses
 
     def _replay(self, data, targets):
+        if self._stale_graph:
+            raise RuntimeError("TrainStep: this step's captured graph contains the AdamW update, and an EAGER optimizer step ran "
+                               "after the capture; replaying the graph now faults on the GPU (tools/replay_after_eager.py, DESIGN.md "
+                               "section 12).  Capture again (drop_graph() + capture()), or keep to one mode.")
         if data.data_ptr() != self._static_x.data_ptr():
             self._static_x.copy_(data)
         if targets is not self._static_t:
@@ -336,6 +343,7 @@ class TrainStep:
     def drop_graph(self):
         """Back to the eager step (with its overlapped gradient exchange)."""
         self._graph = None
+        self._captured_with_optimizer = self._stale_graph = False
         self._static_counts = None
         self._static_counts_local = None
         self.reducer.overlap = True
@@ -370,4 +378,6 @@ class TrainStep:
         self.reducer.finish()
         self._clip()
         self.optimizer.step()
+        if self._captured_with_optimizer:
+            self._stale_graph = True       # see _replay
         return total.detach(), losses
