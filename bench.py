@@ -62,10 +62,10 @@ def msda_algorithmic_bytes(kind, N, S, M, C, L, Lq, P, e, e_loc):
 
 
 BWD_KINDS = ("bwd_query", "cell_count", "scan", "cell_fill", "pull", "value_tile", "value_cells", "bwd_generic")
-PMC_FILE = "r05_msda_pmc_step.json"
+PMC_FILE = "r06_msda_pmc_step.json"
 # the backward as the training step runs it (round 4: transoar_msda3d_backward_proj, bf16 grad_proj instead of fp32
 # grad_loc / grad_attn): FETCH_SIZE / WRITE_SIZE passes of `tools/bench_msda.py --proj`
-PMC_BWD_FILE = "r05_msda_pmc_step.json"
+PMC_BWD_FILE = "r06_msda_pmc_step.json"
 
 
 def pmc_traffic(kind, dims):

@@ -17,7 +17,7 @@ python bench.py --no-graph --no-cpu-baseline > $O/${T}_bench_eager.json 2> /dev/
 python bench.py --no-refine --no-cpu-baseline > $O/${T}_bench_no_refine.json 2> /dev/null; one $O/${T}_bench_no_refine.json
 bash tools/profile_step.sh ${T} > /dev/null 2>&1; head -12 $O/${T}_bench_eager_by_family.txt
 bash tools/collect_msda_pmc.sh $O/${T}_msda_pmc > /dev/null 2>&1; cp $O/${T}_msda_pmc/summary.json $O/${T}_msda_pmc.json
-CMD="python bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline" PASSES="1 2 3" bash tools/collect_msda_pmc.sh $O/${T}_msda_pmc_step > /dev/null 2>&1; cp $O/${T}_msda_pmc_step/summary.json $O/${T}_msda_pmc_step.json
+CMD="env TRANSOAR_BENCH_SKIP_OTHER=1 python bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline" PASSES="1 2 3" bash tools/collect_msda_pmc.sh $O/${T}_msda_pmc_step > /dev/null 2>&1; cp $O/${T}_msda_pmc_step/summary.json $O/${T}_msda_pmc_step.json
 python tools/bench_msda.py --iters 20 --dtypes bf16 > $O/${T}_msda_op_bench.jsonl 2>/dev/null; cut -c1-200 $O/${T}_msda_op_bench.jsonl
 python tools/bench_msda.py --iters 20 --dtypes bf16 --proj > $O/${T}_msda_op_bench_proj.jsonl 2>/dev/null
 python tools/check_pcm.py --dists model,init,uniform,wide > $O/${T}_msda_fwd_kernels.jsonl 2>/dev/null; tail -3 $O/${T}_msda_fwd_kernels.jsonl
@@ -33,6 +33,6 @@ python tools/bench_roi_attn.py > $O/${T}_roi_attn_bench.jsonl 2>/dev/null; tail 
 (python tools/bench_win_attn.py; python tools/bench_win_attn.py --shifted) > $O/${T}_win_attn_bench.jsonl 2>/dev/null; head -2 $O/${T}_win_attn_bench.jsonl | cut -c1-220
 python tools/bench_gelu_mlp.py > $O/${T}_gelu_mlp_bench.jsonl 2>/dev/null; head -1 $O/${T}_gelu_mlp_bench.jsonl | cut -c1-300
 # (the raw counter files of these two passes are tens of MB: they stay in /tmp, only the per-kernel summaries come back)
-(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_all "" -- python $OLDPWD/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_all.txt > $O/${T}_pmc_rank.txt; head -6 $O/${T}_pmc_rank.txt
-(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_swin_all "" -- python $OLDPWD/bench.py --swin --no-refine --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_swin_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_swin_all.txt > $O/${T}_pmc_rank_swin.txt
+(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_all "" -- env TRANSOAR_BENCH_SKIP_OTHER=1 python $OLDPWD/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_all.txt > $O/${T}_pmc_rank.txt; head -6 $O/${T}_pmc_rank.txt
+(cd /tmp; bash $OLDPWD/tools/pmc_any.sh /tmp/${T}_pmc_swin_all "" -- env TRANSOAR_BENCH_SKIP_OTHER=1 python $OLDPWD/bench.py --swin --no-refine --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/${T}_pmc_swin_all.txt 2>&1); python tools/pmc_rank.py $O/${T}_pmc_swin_all.txt > $O/${T}_pmc_rank_swin.txt
 [ -n "${SKIP_CPU_STEP:-}" ] || { python bench.py --cpu-baseline-only --cpu-baseline-step > $O/${T}_cpu_step.json 2>/dev/null; tail -1 $O/${T}_cpu_step.json | cut -c1-300; }

@@ -508,12 +508,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
   const BrickOrder& order = *order_p;
   constexpr int P = 4, C = 64, KB = kMmaKB, VP = kMmaVP, WR = kMmaWRows;
   __shared__ __attribute__((aligned(16))) unsigned char vbuf[KB * VP];
-  // G block [row][query] (+ a zero spare row); the cell histogram before that.  Rows are GS = 40 words apart, not 32: the two
-  // halves of the wave store MFMA rows 4 apart, and 4 x 40 words = 32 banks puts them into disjoint halves of the 64 banks
-  // (at 32 words both halves hit banks 0..31: every one of the 16 stores per tile was a 2-way conflict -- 41 % of the
-  // kernel's LDS cycles, profiles/r05_pmc_rank.txt)
-  constexpr int GS = 40;
-  __shared__ __attribute__((aligned(16))) float gbuf[WR * GS];
+  __shared__ __attribute__((aligned(16))) float gbuf[WR * 32];      // G block [row][query] (+ a zero spare row); the cell histogram before that
 
   const long u = xcd_contiguous_block(blockIdx.x, n_units);
   if (u < 0) return;
@@ -556,7 +551,7 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
     mma_level_points<LT>(order, l, live, item, LP, kg, loc, attn, pt[l], box[l], a_in[l]);
   });
 
-  for (int i = lane; i < WR * GS / 4; i += 64) reinterpret_cast<float4*>(gbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < WR * 32 / 4; i += 64) reinterpret_cast<float4*>(gbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
   for (int i = lane; i < KB * VP / 16; i += 64) reinterpret_cast<float4*>(vbuf)[i] = float4{0.f, 0.f, 0.f, 0.f};
 
   const int st_row = lane >> 3, st_vec = lane & 7;
@@ -687,17 +682,17 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
       const MmaPoint g = pt[l][pi];
       const int d0 = (g.dhw & 1023) - 1, h0 = ((g.dhw >> 10) & 1023) - 1, w0 = ((g.dhw >> 20) & 1023) - 1;
       const bool okp = g.dhw != 0x3fffffff;
-      const int cb = (__mul24(__mul24(d0 - bx.bd, bx.TH) + (h0 - bx.bh), bx.TW) + (w0 - bx.bw)) * GS + j;
+      const int cb = (__mul24(__mul24(d0 - bx.bd, bx.TH) + (h0 - bx.bh), bx.TW) + (w0 - bx.bw)) * 32 + j;
       const bool vd[2] = {okp && static_cast<unsigned>(d0) < static_cast<unsigned>(D), okp && static_cast<unsigned>(d0 + 1) < static_cast<unsigned>(D)};
       const bool vh[2] = {static_cast<unsigned>(h0) < static_cast<unsigned>(H), static_cast<unsigned>(h0 + 1) < static_cast<unsigned>(H)};
       const bool vw[2] = {static_cast<unsigned>(w0) < static_cast<unsigned>(W), static_cast<unsigned>(w0 + 1) < static_cast<unsigned>(W)};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int dd = c >> 1, dh = c & 1;
-        const int col = cb + (dd ? THW * GS : 0) + (dh ? bx.TW * GS : 0);
+        const int col = cb + (dd ? THW * 32 : 0) + (dh ? bx.TW * 32 : 0);
 #pragma unroll
         for (int dw = 0; dw < 2; ++dw) {
-          ecol[pi * 8 + 2 * c + dw] = (vd[dd] && vh[dh] && vw[dw]) ? col + GS * dw : -64;
+          ecol[pi * 8 + 2 * c + dw] = (vd[dd] && vh[dh] && vw[dw]) ? col + 32 * dw : -64;
           dots[pi * 8 + 2 * c + dw] = 0.f;
         }
       }
@@ -788,12 +783,12 @@ __global__ __launch_bounds__(64, 2) void msda3d_bwd_query_mma(
             acc = Mma<VT>::mfma(a, gof[sk], acc);
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) gbuf[(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * GS + j] = acc[r];
+          for (int r = 0; r < 16; ++r) gbuf[(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + j] = acc[r];
         }
         // ---- every lane's corner dots (a corner outside this block reads the zero spare row)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          dots[e] += gbuf[min(static_cast<unsigned>(ecol[e] - k0 * GS), static_cast<unsigned>(KB * GS + j))];
+          dots[e] += gbuf[min(static_cast<unsigned>(ecol[e] - k0 * 32), static_cast<unsigned>(KB * 32 + j))];
       }
     }
 
