@@ -2,14 +2,14 @@
 //
 // Semantics: SURVEY.md appendix A (ops/src/cuda/ms_deform_im2col_cuda.cuh:31-114, 370-439).
 //
-// msda3d_pcm.hpp (round 3) gave a wave 8 queries: 1 363 VALU instructions and 256 staged rows (32 KB of L2 requests)
-// per wave, most of it the price of carving the problem into wave-sized pieces -- unit decode with five integer
-// divisions, a box reduction, a parameter block through LDS, row staging for a box that 8 queries barely share.
-// Three rounds of variants kept that carving.  This kernel changes it:
+// MEASURED SLOWER than msda3d_pcm.hpp (1.05 / 0.81 ms against 0.66 / 0.50 at the flagship shape) and
+// therefore behind TRANSOAR_MSDA3D_Q16: this is the speed-of-light probe of the carving round 5's review asked for, kept
+// parity-tested.  What it set out to do against msda3d_pcm.hpp (8 queries per wave, 1 363 vector instructions and 256 staged
+// rows per wave):
 //
-//   * one wave owns 16 queries (a 2x2x4 sub-brick of a 4x4x8 brick) of one head and walks UPW consecutive units
-//     (the sub-bricks of one brick first): the box of 16 queries is ~0.8x the rows of the box of 8, so rows staged
-//     per query fall 2.5x, and everything that is per wave or per K-block is shared by twice the queries;
+//   * one wave owns 16 queries (a 2x2x4 sub-brick of a 4x4x8 brick) of one head and walks UPW consecutive units (the sub-bricks
+//     of one brick first).  The box of 16 queries turned out 1.29x the box of 8 (322 against 250 rows on jittered locations):
+//     rows staged per query fall 1.55x, matrix work per query rises 1.27x;
 //   * lane = (query, point) = one MFMA column, for all four levels: 4 points of geometry per lane, no exchange
 //     between wave halves, its 8 corner weights per level go to its OWN weight column in LDS;
 //   * the weight block is two bf16 planes (hi and lo halves of every weight, 2^-16 together) [column][K-slot]:
