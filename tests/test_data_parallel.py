@@ -218,3 +218,51 @@ def test_eight_replicas_bf16_wire_two_steps(_restore_mask_table):
     print(res["worst"])
     # every rank's gradient is rounded to bf16 once (2^-9 of its own magnitude); the sum of 8 such terms against the exact sum
     assert res["worst"][0][0] <= 2.0 ** -5, res["worst"]
+
+
+def _skipped_branch_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transoar_amd.data_parallel import GradientAllReducer
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk, self.side, self.head = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4)
+
+        def forward(self, x, use_side):
+            h = torch.tanh(self.trunk(x))
+            if use_side:
+                h = h + torch.tanh(self.side(h))
+            return self.head(h)
+
+    net = Net()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=1e-2)
+    red = GradientAllReducer(net, bucket_bytes=1 << 9)
+    x = torch.randn(2, 8, 16)
+    for it in range(3):
+        red.begin()
+        # step 0: every rank takes the side branch (so it is a live parameter); afterwards only rank 0 does
+        net(x[rank], use_side=(it == 0 or rank == 0)).square().sum().backward()
+        red.finish()
+        assert all(p.grad is not None for p in net.parameters()), "a live parameter lost its gradient on rank %d" % rank
+        opt.step()
+    chk = torch.cat([p.detach().double().reshape(-1) for p in net.parameters()])
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    if rank == 0:
+        torch.save({"same": bool(torch.equal(gathered[0], gathered[1])), "side_moved": float(net.side.weight.grad.abs().sum())}, out_path)
+    dist.destroy_process_group()
+
+
+def test_live_parameter_without_gradient_on_one_rank_keeps_replicas_identical():
+    """Round-5 ADVICE (medium): a live parameter whose branch is skipped on ONE rank got a zero slice in the exchange but kept
+    .grad = None there, so that rank's optimizer skipped it while the others stepped it with the summed gradient (weight decay
+    and moments included) -- the replicas drifted.  Its .grad is the bucket view on every rank now."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "out.pt")
+        port = 35500 + (os.getpid() % 2000)
+        mp.spawn(_skipped_branch_worker, args=(2, port, out_path), nprocs=2, join=True)
+        res = torch.load(out_path)
+    assert res["same"] and res["side_moved"] > 0, res

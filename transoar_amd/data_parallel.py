@@ -78,6 +78,7 @@ class GradientAllReducer:
         self.overlap = True          # launch a bucket's all-reduce from the autograd hook
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets, self._bucket_of, self._hooks = [], {}, []
+        self._next = 0               # first bucket of this step that has not been launched yet
         self._fired, self._first_step, self._dead = set(), True, set()
         if not self.flat:
             return
@@ -127,6 +128,7 @@ class GradientAllReducer:
         for b in self.buckets:
             b.pending = b.expected
             b.handle = None
+        self._next = 0
         self._fired.clear()
 
     def _pack(self, b):
@@ -159,7 +161,21 @@ class GradientAllReducer:
         if b.pending == 0:
             self._pack(b)
             if self.overlap and self.active:
-                b.handle = self._launch(b)
+                self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch, in BUCKET ORDER, every packed bucket up to the first one that is not complete yet.  Every rank must issue
+        its collectives in the same order; launched the moment each bucket fills up, a rank on which some bucket stays
+        incomplete until the end of the backward (a live parameter whose branch it skipped this step) would issue that bucket
+        last while the other ranks issue it in the middle -- mismatched collectives (gloo aborts, RCCL hangs or sums the wrong
+        buffers; tests/test_data_parallel.py::test_live_parameter_without_gradient...).  Buckets are numbered in the order
+        autograd completes them, so in the normal case this launches exactly when the hook fires."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.pending != 0 or b.handle is not None:
+                break
+            b.handle = self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
         if b.wire is not None:
@@ -181,12 +197,13 @@ class GradientAllReducer:
     def exchange(self):
         """Launch every bucket that is not in flight yet, wait for all of them and widen compressed buckets back
         (the tail of the eager step, and the whole exchange of the captured step, which has no hooks running)."""
-        for b in self.buckets:
-            if b.handle is None:     # eager: first step only (a parameter without gradient held the bucket back)
+        for b in self.buckets:       # in bucket order, like the hooks (see _launch_ready)
+            if b.handle is None:     # a parameter without a gradient held the bucket -- and every later one -- back
                 if b.pending > 0:
                     self._pack(b)
                     b.pending = 0
                 b.handle = self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             b.handle.wait()
             if b.wire is not None:
