@@ -60,11 +60,20 @@ class FlatAdamW(torch.optim.AdamW):
         sig = tuple(t.data_ptr() for r in rows for t in r)
         hit = self._tables.get(sig)
         if hit is not None:
+            if torch.cuda.is_current_stream_capturing() and not hit[5]:
+                # an eager entry found again while capturing (data-parallel: the bucket views have the same addresses in the
+                # warm-up steps and in the capture): the graph bakes this table's address in, so it must never be evicted
+                hit = self._tables[sig] = hit[:5] + (True,)
             return hit
         import numpy as np
         tab = np.zeros((len(rows), 8), dtype=np.int64)
         ids, offs = [], []
         for i, (p, g, m, v, lr, st) in enumerate(rows):
+            if p.numel() % 4 == 0 and any(t.data_ptr() % 16 for t in (p, g, m, v)):
+                # the kernel's float4 path (n % 4 == 0) needs 16-byte aligned pointers: a view at an odd offset of a storage
+                # would fault.  torch allocations and the reducer's bucket views (128-byte aligned) are.  (Checked when a work
+                # table is made, i.e. once per set of addresses.)
+                raise ValueError("FlatAdamW: parameter, gradient and moments must be 16-byte aligned")
             tab[i, :6] = [p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(), st.data_ptr()]
             tab[i, 6] = p.numel()
             for off in range(0, p.numel(), CHUNK):
@@ -129,7 +138,12 @@ class FlatAdamW(torch.optim.AdamW):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.float().contiguous()
-                rows.append((p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], st["step"]))
+                lr = group["lr"]
+                if lr.dtype != torch.float32 or lr.device != p.device:        # e.g. a state dict loaded with map_location="cpu"
+                    lr = group["lr"] = lr.to(device=p.device, dtype=torch.float32)
+                if device is not None and p.device != device:
+                    raise ValueError("FlatAdamW: every parameter must live on one device (one launch, one work table)")
+                rows.append((p, g, st["exp_avg"], st["exp_avg_sq"], lr, st["step"]))
                 steps.append(st["step"])
                 device = p.device
         if not rows:

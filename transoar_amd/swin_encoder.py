@@ -131,6 +131,10 @@ class _BiasLookup(torch.autograd.Function):
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
         out = torch.zeros((ctx.rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        if g.is_cuda and torch.are_deterministic_algorithms_enabled():
+            # index_add_ accumulates with float atomics on the GPU: run-to-run differences in the last bits.  Under
+            # torch.use_deterministic_algorithms the sorted accumulation of index_put_ (what table[index]'s own backward uses)
+            return out.index_put_((index,), g.contiguous(), accumulate=True), None
         return out.index_add_(0, index, g.contiguous()), None
 
 
