@@ -471,8 +471,11 @@ __global__ __launch_bounds__(64, kPcmKW == 32 ? 4 : 3) void msda3d_fwd_pcm(
           have_pre = true;
         }
       }
-      // ---- 16-row chunks on the matrix cores
-      for (int kc = 0; kc < nch; ++kc) {
+      // ---- 16-row chunks on the matrix cores (unrolled: the second chunk's reads are the first one's at immediate offsets --
+      // as a run-time loop three address registers were stepped per chunk, 48 vector instructions per wave)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        if (kc >= nch) break;
         const unsigned* wp = wcol + sub * KB + kc * 16 + 8 * kh;
         const u32x4 p0 = *reinterpret_cast<const u32x4*>(wp);
         const u32x4 p1 = *reinterpret_cast<const u32x4*>(wp + 4);
