@@ -136,9 +136,23 @@ class TrainStep:
             if pending is not None:
                 pending.wait()
             losses = self.criterion(out, targets, seg_targets, self.model._anchors)
-            coefs = self.config["loss_coefs"]
-            total = sum(v * coefs[k.split("_")[0]] for k, v in losses.items())
+            total = self._weighted_total(losses)
         return total, losses
+
+    def _weighted_total(self, losses):
+        """sum_k coef[k] * loss[k] as ONE stack and one dot product (eleven multiplies and ten adds, and as many nodes in the
+        backward, were 40 launches of ~5 us per step)."""
+        coefs = self.config["loss_coefs"]
+        vals = list(losses.values())
+        dt = vals[0].dtype
+        for v in vals[1:]:
+            dt = torch.promote_types(dt, v.dtype)
+        key = (tuple(losses.keys()), vals[0].device, dt)
+        cached = getattr(self, "_coef_vec", None)
+        if cached is None or cached[0] != key:
+            w = torch.tensor([float(coefs[k.split("_")[0]]) for k in losses], dtype=dt, device=vals[0].device)
+            cached = self._coef_vec = (key, w)
+        return torch.dot(torch.stack([v.to(dt) for v in vals]), cached[1])
 
     # ---- captured-graph mode ------------------------------------------------------------------
     # The eager step is close to host-bound on one MI355X (~2000 kernel launches: 56 ms of enqueue for
