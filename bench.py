@@ -264,13 +264,13 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--graph", action="store_true",
-                    help="replay forward+loss+backward as one HIP graph: the default on one GPU (about 2 ms faster per "
-                         "step at K=10, host enqueue 9 ms instead of 56 ms).  With more than one rank the default is the "
-                         "eager step, whose bucketed all-reduce overlaps the backward (DESIGN.md sections 6 and 8)")
+                    help="replay the whole step (forward + loss + backward [+ all-reduce] + AdamW) as one HIP graph instead of "
+                         "the eager step (host enqueue 3 ms per step instead of 17; 0.1-0.45 ms slower per step on one GPU, "
+                         "DESIGN.md section 12.4).  The eager step's bucketed all-reduce overlaps the backward (sections 6, 8)")
     ap.add_argument("--swin", action="store_true", help="BASELINE config #4: Swin encoder stages (use_encoder_attn=True)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager step also on one GPU")
+    ap.add_argument("--no-graph", action="store_true", help="the eager step (the default since round 6; kept for old command lines)")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-step", action="store_true",
@@ -315,8 +315,12 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
-    if not args.graph and (world > 1 or dist.is_initialized()):
-        args.no_graph = True                   # data-parallel default: eager step with the overlapped exchange
+    if not args.graph:
+        # The eager step is the default on every rank count (round 6).  Rounds 2-5 replayed one HIP graph per step on one
+        # GPU because the eager step was host-bound; with the synchronous copy gone from the optimizer
+        # the host needs 16-19 ms to enqueue a 32-ms step, and the eager step measures 0.1-0.45 ms FASTER than the graph
+        # replay on every box of the round (profiles/r06_bench_*).  --graph replays the captured step.
+        args.no_graph = True
     step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -363,9 +367,6 @@ def main():
         step(x, targets)
         trace("warmup %d" % i)
     barrier()
-    if step._graph is None:                    # eager: time the kernels over the timed steps themselves
-        _native.profile_enable(True)
-        _native.profile_read()
     t0 = time.perf_counter()
     host_s = 0.0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # hipEvents on the compute stream
@@ -398,32 +399,24 @@ def main():
             ts.append(time.perf_counter() - h0)
         torch.cuda.synchronize()
         return round(sorted(ts[1:])[(n - 1) // 2] * 1e3, 2)
-    prof = None
-    if step._graph is None:                    # eager: the library's event pairs of the timed steps, before anything else runs
-        _native.profile_enable(False)
-        prof = _native.profile_read()
     host_drained = {"timed_mode": drained()}
-    # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the
-    # launch stream.  A replayed graph re-records nothing, so in graph mode they come from eager steps of
-    # the same model state run right after the timed replays (kernel durations do not depend on how the
-    # launch was issued); in eager mode they are taken over the timed steps themselves.
-    prof_steps = args.steps
-    if step._graph is not None:
-        graph, step._graph = step._graph, None
+    # per-kernel durations of the MSDeformAttn kernels: hipEvent pairs recorded by the library on the launch stream, over
+    # three eager steps of the same model state run right after the timed region (the timed steps themselves carry no
+    # profiling events; a replayed graph re-records nothing anyway; kernel durations do not depend on how the launch was issued)
+    graph, step._graph = step._graph, None
+    if graph is not None:
         step.reducer.overlap = True
-        prof_steps = 3
-        _native.profile_enable(True)
-        _native.profile_read()
-        for i in range(prof_steps):
-            step(x, targets)
-            trace("eager profile step %d" % i)
-        torch.cuda.synchronize()
-        _native.profile_enable(False)
-        prof = _native.profile_read()
-        host_drained["eager"] = drained()
-        step._graph = graph
-    else:
-        host_drained["eager"] = host_drained["timed_mode"]
+    prof_steps = 3
+    _native.profile_enable(True)
+    _native.profile_read()
+    for i in range(prof_steps):
+        step(x, targets)
+        trace("eager profile step %d" % i)
+    torch.cuda.synchronize()
+    _native.profile_enable(False)
+    prof = _native.profile_read()
+    host_drained["eager"] = drained() if graph is not None else host_drained["timed_mode"]
+    step._graph = graph
     other_states = None
     if rank == 0 and not args.no_refine and not args.fp32 and not args.swin and not os.environ.get("TRANSOAR_BENCH_SKIP_OTHER"):
         try:
@@ -447,8 +440,7 @@ def main():
         for kind, (ms, n) in prof.items():
             if n:
                 kernels[kind] = {"launches_per_step": n / prof_steps, "avg_ms": round(ms / n, 4)}
-        timing = "hipEvent pairs on the launch stream, " + (
-            "timed steps" if step_mode.startswith("eager") else "3 eager steps right after the timed graph replays")
+        timing = "hipEvent pairs on the launch stream, 3 eager steps right after the timed region"
         roofline = msda_bwd = None
         if "fwd" in kernels:                    # the MSDeformAttn forward gather: the kernel north_star names
             b = msda_algorithmic_bytes("fwd", **dims)
