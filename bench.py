@@ -388,8 +388,7 @@ def main():
     # what the host needs to enqueue ONE step into an EMPTY queue (host_enqueue_ms_per_step above is taken with the GPU running
     # behind: once the queue is full it measures back-pressure, i.e. the step time again).  The mode that was timed here; the eager
     # step (the data-parallel default, one process per GPU: what 8 ranks on one host contend with) below, among the eager
-    # profile steps.  (A captured whole-step graph must not be replayed again after EAGER optimizer steps of the same TrainStep:
-    # measured to fault, tools/replay_after_eager.py, DESIGN section 12 -- hence the order.)
+    # profile steps.
     def drained(n=4):
         ts = []
         for _ in range(n):

@@ -165,9 +165,11 @@ class FocusedAttn(nn.Module):
                 if const_pos:
                     if cache is None:
                         cache = k_pos._transoar_roi_gather = {}
-                    if len(cache) >= 8:
-                        cache.clear()
-                    cache[key] = hit
+                    if len(cache) < 8:
+                        # entries are never dropped while the positional tokens live: a captured graph may hold an entry's
+                        # address (a freed one is reused by the next allocation on its stream); past eight index lists /
+                        # versions the gather simply runs every time
+                        cache[key] = hit
             k_tok = v_tok + hit[1]
         else:
             k_tok = v_tok + k_pos.index_select(1, flat.long())

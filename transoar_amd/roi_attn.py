@@ -51,11 +51,14 @@ def _check(rc, what):
 def key_mask(pad):
     """pad (O, L) bool, True = padding -> (keybits (O, ceil(L/32)) int32: bit i of word t = key 32 t + i is masked, the
     bits past L set; n_tiles (O) int32: leading 32-key tiles that hold a real key).  Cached on the tensor (the RoI
-    lists are fixed at construction)."""
+    lists are fixed at construction), per (address, version): entries are only ever ADDED -- a captured graph may hold the
+    address of an older entry's tensors, and a freed one is handed to the next allocation on its stream (DESIGN.md section
+    12.4: the kernel then read its tile counts out of someone else's data)."""
     key = (pad.data_ptr(), pad._version, str(pad.device), tuple(pad.shape))
-    hit = getattr(pad, "_transoar_key_mask", None)
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+    cache = getattr(pad, "_transoar_key_mask", None)
+    hit = None if cache is None else cache.get(key)
+    if hit is not None:
+        return hit
     n_org, n_keys = pad.shape
     tiles = (n_keys + 31) // 32
     full = torch.ones(n_org, tiles * 32, dtype=torch.bool, device=pad.device)
@@ -67,7 +70,9 @@ def key_mask(pad):
     last = (live.to(torch.int64) * torch.arange(1, tiles * 32 + 1, device=pad.device)).amax(1)        # index of the last real key + 1
     n_tiles = ((last + 31) // 32).to(torch.int32).contiguous()
     try:
-        pad._transoar_key_mask = (key, words, n_tiles)
+        if cache is None:
+            cache = pad._transoar_key_mask = {}
+        cache[key] = (words, n_tiles)          # a few hundred bytes per entry
     except Exception:        # noqa: BLE001  (a tensor subclass that refuses attributes: just do not cache)
         pass
     return words, n_tiles

@@ -63,8 +63,6 @@ class TrainStep:
         # gradient tensor (no zero-fill of buckets, no per-parameter accumulate kernel: ~170 launches less per step)
         self.reducer = GradientAllReducer(model, process_group, bucket_bytes, always_flat=False)
         self._graph = None
-        self._stale_graph = False          # an eager optimizer step ran after a capture that holds the AdamW update
-        self._captured_with_optimizer = False
         self._replay_done = None
         self._static_counts = None
         self._static_counts_local = None
@@ -262,15 +260,15 @@ class TrainStep:
             raise RuntimeError("graph replay gives loss %r, the eager step gave %r" % (got, expect))
         self._expect_total = None
         self._graph = graph
-        self._captured_with_optimizer, self._stale_graph = bool(self.capture_optimizer), False
         # TRANSOAR_GRAPH_SERIALIZE=1: never launch the graph again before its previous launch has finished on the GPU
         self._replay_done = torch.cuda.Event() if os.environ.get("TRANSOAR_GRAPH_SERIALIZE") else None
         return self
 
     def _snapshot(self):
-        """Copies of every parameter and module buffer, of the optimizer's state tensors (None where the state does not
-        exist yet) and of the device's RNG state (the warm-up steps and the verification replay draw dropout seeds)."""
-        params = [p.detach().clone() for p in list(self.model.parameters()) + list(self.model.buffers())]
+        """Copies of every parameter and module buffer (with the version counter each had), of the optimizer's state tensors
+        (None where the state does not exist yet) and of the device's RNG state (the warm-up steps and the verification replay
+        draw dropout seeds)."""
+        params = [(p.detach().clone(), p._version) for p in list(self.model.parameters()) + list(self.model.buffers())]
         self._snap_rng = torch.cuda.get_rng_state(next(self.model.parameters()).device)
         state = []
         for group in self.optimizer.param_groups:
@@ -281,12 +279,21 @@ class TrainStep:
 
     def _restore(self, snap):
         """In place (the captured graph holds the addresses): parameters back to the snapshot, optimizer state back to
-        the snapshot or -- where it was created after the snapshot -- to its initial zeros."""
+        the snapshot or -- where it was created after the snapshot -- to its initial zeros.
+
+        A tensor whose version counter still has the snapshot's value was never written by the warm-up steps, and the captured
+        step is the same code, so a replay does not write it either: it is left alone.  This is not an optimisation.  copy_
+        advances the version counter, and derived data is cached per (tensor, version) -- the RoI key masks on `roi_pad`
+        (roi_attn.key_mask), the gathered positional tokens (focused_decoder) -- so a restore that "rewrote" those constant
+        buffers made the next eager forward rebuild the derived tensors and FREE the ones whose addresses the graph had just
+        baked in: the next tensors allocated on that stream landed in them, and the replay read tile counts out of someone
+        else's data (round 6: a memory access fault in roi_attn_fwd)."""
         params, state = snap
         torch.cuda.set_rng_state(self._snap_rng, next(self.model.parameters()).device)
         with torch.no_grad():
-            for p, c in zip(list(self.model.parameters()) + list(self.model.buffers()), params):
-                p.copy_(c)
+            for p, (c, version) in zip(list(self.model.parameters()) + list(self.model.buffers()), params):
+                if p._version != version:
+                    p.copy_(c)
             i = 0
             for group in self.optimizer.param_groups:
                 for p in group["params"]:
@@ -320,10 +327,6 @@ class TrainStep:
         return total.detach(), losses
 
     def _replay(self, data, targets):
-        if self._stale_graph:
-            raise RuntimeError("TrainStep: this step's captured graph contains the AdamW update, and an EAGER optimizer step ran "
-                               "after the capture; replaying the graph now faults on the GPU (tools/replay_after_eager.py, DESIGN.md "
-                               "section 12).  Capture again (drop_graph() + capture()), or keep to one mode.")
         if data.data_ptr() != self._static_x.data_ptr():
             self._static_x.copy_(data)
         if targets is not self._static_t:
@@ -357,7 +360,6 @@ class TrainStep:
     def drop_graph(self):
         """Back to the eager step (with its overlapped gradient exchange)."""
         self._graph = None
-        self._captured_with_optimizer = self._stale_graph = False
         self._static_counts = None
         self._static_counts_local = None
         self.reducer.overlap = True
@@ -392,6 +394,4 @@ class TrainStep:
         self.reducer.finish()
         self._clip()
         self.optimizer.step()
-        if self._captured_with_optimizer:
-            self._stale_graph = True       # see _replay
         return total.detach(), losses
