@@ -125,6 +125,8 @@ class FlatAdamW(torch.optim.AdamW):
                 (betas, eps, wd) = cfg
             elif cfg != (betas, eps, wd):
                 raise ValueError("FlatAdamW: betas / eps / weight_decay must be the same in every group (only lr differs)")
+            if group.get("amsgrad") or group.get("maximize"):          # (a loaded state dict can switch them on after __init__)
+                raise ValueError("FlatAdamW: amsgrad / maximize are not implemented")
             if not torch.is_tensor(group["lr"]):            # (a state dict written next to a plain AdamW was loaded)
                 group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=group["params"][0].device)
             for p in group["params"]:
