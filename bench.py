@@ -264,13 +264,15 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (config batch_size)")
     ap.add_argument("--no-refine", action="store_true", help="shipped default: use_decoder_attn=False")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step (forward + loss + backward [+ all-reduce] + AdamW) as one HIP graph instead of "
-                         "the eager step (host enqueue 3 ms per step instead of 17; 0.1-0.45 ms slower per step on one GPU, "
-                         "DESIGN.md section 12.4).  The eager step's bucketed all-reduce overlaps the backward (sections 6, 8)")
+                    help="replay the whole step (forward + loss + backward [+ all-reduce] + AdamW) as one HIP graph (host enqueue "
+                         "3 ms per step instead of 17).  Default on ONE GPU: both modes are paced during the warm-up and the "
+                         "faster one is timed (they are within 1.5 %% of each other, which one leads depends on the host: "
+                         "DESIGN.md section 12.4); on more than one GPU the eager step, whose bucketed all-reduce overlaps the "
+                         "backward (sections 6, 8)")
     ap.add_argument("--swin", action="store_true", help="BASELINE config #4: Swin encoder stages (use_encoder_attn=True)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="the eager step (the default since round 6; kept for old command lines)")
+    ap.add_argument("--no-graph", action="store_true", help="the eager step, without pacing the graph replay first")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-baseline-step", action="store_true",
@@ -315,11 +317,12 @@ def main():
     torch.manual_seed(0)                       # identical replicas
     model = TransoarNet(cfg).to(dev)
     amp = torch.float32 if args.fp32 else torch.bfloat16
-    if not args.graph:
-        # The eager step is the default on every rank count (round 6).  Rounds 2-5 replayed one HIP graph per step on one
-        # GPU because the eager step was host-bound; with the synchronous copy gone from the optimizer
-        # the host needs 16-19 ms to enqueue a 32-ms step, and the eager step measures 0.1-0.45 ms FASTER than the graph
-        # replay on every box of the round (profiles/r06_bench_*).  --graph replays the captured step.
+    # One GPU, no flag: capture the step, pace graph replay and eager step for 8 steps each during the warm-up and time the
+    # faster one (round 6: with the synchronous copy gone from the optimizer the host needs 16-19 ms to enqueue a 32-ms step,
+    # and the eager step measured 0.1-0.45 ms FASTER than the replay on every box of the round; a slower or busier host turns
+    # that around, and the replay needs 3 ms of host time per step).  More than one GPU, no flag: the eager step.
+    auto = not args.graph and not args.no_graph and world == 1
+    if not args.graph and not auto:
         args.no_graph = True
     step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=amp, graph=not args.no_graph)
 
@@ -363,6 +366,29 @@ def main():
             step_mode = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120],)
             step.drop_graph()
     trace("capture done: %s" % step_mode)
+    calibration = None
+    if auto and step._graph is not None:
+        def pace(n=8):
+            step(x, targets)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step(x, targets)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        t_graph = pace()
+        graph, step._graph = step._graph, None
+        step.reducer.overlap = True
+        t_eager = pace()
+        calibration = {"graph_ms": round(t_graph, 3), "eager_ms": round(t_eager, 3), "steps_each": 8,
+                       "note": "wall clock per step over 8 steps of each mode during the warm-up; the faster mode is the one timed"}
+        if t_eager <= t_graph:
+            step.drop_graph()
+            step_mode = "eager"
+        else:
+            step._graph = graph
+            step.reducer.overlap = bool(getattr(step, "capture_exchange", False))
+        trace("paced: graph %.3f ms, eager %.3f ms -> %s" % (t_graph, t_eager, step_mode))
     for i in range(args.warmup):
         step(x, targets)
         trace("warmup %d" % i)
@@ -482,7 +508,7 @@ def main():
                                                                        ", Swin encoder (configs[3])" if args.swin else ""),
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "volume": list(cfg["volume_shape"]),
                        "parallelism": "dp%d" % world, "weights": "random init", "optimizer": "AdamW fused",
-                       "step_mode": step_mode,
+                       "step_mode": step_mode, "step_mode_pacing": calibration,
                        "params": sum(p.numel() for p in model.parameters())},
             "loss": round(loss_value, 5), "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
             "host_enqueue_drained_ms": dict(host_drained, note="host time to enqueue one step into an EMPTY queue (median of 3 after a "
