@@ -34,6 +34,7 @@ import sys
 import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see transoar_amd/__init__.py; before torch loads HIP
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL between ranks; must be set before HSA initialises
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
