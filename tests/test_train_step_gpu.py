@@ -331,3 +331,47 @@ def test_captured_data_parallel_step():
     # between runs (0.2 typical; one full-suite run in two crossed 0.6).  Bounded: the median and the 90th percentile tightly,
     # the worst tensor below 1 -- a tensor the captured path never updated, or updated twice, would sit at exactly 1
     assert out["update_rel_median"] <= 0.05 and out["update_rel_p90"] <= 0.3 and out["update_rel_worst"][0] <= 0.9, out
+
+
+@pytest.mark.gpu
+def test_training_step_trains_eager_and_captured():
+    """Step parity says one step is right; this says the steps add up: the flagship model on ONE fixed synthetic batch with
+    AdamW at the reference's learning rates (scripts/train.py:52-63) -- the total loss falls steadily, and the one-graph step
+    follows the eager step's curve from the same initial weights (only the dropout masks differ).  Observed on an MI355X
+    (profiles/r06_train_curve.json, tools/train_curve.py): 22.10 -> 16.1 after 100 steps -> 14.5 after 300 in both modes,
+    the two curves within 1 % of each other at every tenth step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from transoar_amd.config import synthetic_bbox_properties, synthetic_targets, visceral_config
+    from transoar_amd.matcher import DenseTargets
+    from transoar_amd.train_step import TrainStep
+    from transoar_amd.transoarnet import TransoarNet, build_criterion
+    steps = 100
+    curves = {}
+    for graph in (False, True):
+        cfg = visceral_config(refine=True, use_cuda=True)
+        cfg["bbox_properties"] = synthetic_bbox_properties(cfg["num_classes"], seed=0)
+        torch.manual_seed(0)
+        model = TransoarNet(cfg).cuda()
+        step = TrainStep(model, build_criterion(cfg), cfg, amp_dtype=torch.bfloat16, graph=graph)
+        g = torch.Generator(device="cuda").manual_seed(1234)
+        x = torch.rand(2, 1, *cfg["volume_shape"], device="cuda", generator=g)
+        tg = DenseTargets.from_list(synthetic_targets(2, cfg["num_classes"], seed=1, device="cuda"), cfg["num_classes"], "cuda")
+        if graph:
+            step.capture(x, tg)
+        losses = []
+        for i in range(steps + 1):
+            total, _ = step(x, tg)
+            if i % 10 == 0:
+                losses.append(total.detach().float().clone())
+        curves[graph] = torch.stack(losses).cpu().tolist()
+        del step, model
+        torch.cuda.empty_cache()
+    eager, captured = curves[False], curves[True]
+    print("loss every 10 steps, eager:", [round(v, 3) for v in eager], "captured:", [round(v, 3) for v in captured])
+    for c in (eager, captured):
+        assert all(v == v for v in c)
+        assert c[-1] <= 0.8 * c[0], c                                  # observed 0.73
+        assert all(b <= a + 0.02 * c[0] for a, b in zip(c, c[1:])), c   # falling, up to the dropout noise
+    assert abs(eager[0] - captured[0]) <= 2e-3 * eager[0], (eager[0], captured[0])        # same weights, masks differ
+    assert max(abs(a - b) / a for a, b in zip(eager, captured)) <= 0.03, (eager, captured)   # observed <= 1 %
