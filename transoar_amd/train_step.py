@@ -380,6 +380,11 @@ class TrainStep:
             # nodes (and the gradient hooks that launch RCCL from them) keep the stream of the FIRST backward, and a hook
             # firing on another stream inside the capture ends it with a crash in hipStreamEndCapture (tests/_dp_capture_probe.py)
             side = self.capture_stream()
+            if torch.cuda.current_stream(data.device) == side:
+                # the caller runs its loop on the capture stream already (`with torch.cuda.stream(step.capture_stream())`): no
+                # hand-over.  The two waits below drain the GPU's queue at every step boundary -- 0.9 ms of a 32-ms step on an
+                # MI355X (round 6: 32.83 against 31.90 ms) -- so a loop of eager steps of a to-be-captured TrainStep belongs there
+                return self._eager_step(data, targets, seg_targets)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 out = self._eager_step(data, targets, seg_targets)
