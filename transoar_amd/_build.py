@@ -30,6 +30,7 @@ LIBS = {
     "libtransoar_convgemm.so": ["conv_gemm.hip"],
     "libtransoar_attn.so": ["attn.hip"],
     "libtransoar_optim.so": ["optim.hip"],
+    "libtransoar_criterion.so": ["criterion.hip"],
 }
 
 

@@ -141,6 +141,14 @@ class TrainStep:
         """sum_k coef[k] * loss[k] as ONE stack and one dot product (eleven multiplies and ten adds, and as many nodes in the
         backward, were 40 launches of ~5 us per step)."""
         coefs = self.config["loss_coefs"]
+        vec = getattr(losses, "vector", None)
+        if vec is not None:                      # the fused criterion hands its losses over as one tensor already
+            key = (tuple(losses.keys()), vec.device, vec.dtype)
+            cached = getattr(self, "_coef_vec", None)
+            if cached is None or cached[0] != key:
+                w = torch.tensor([float(coefs[k.split("_")[0]]) for k in losses], dtype=vec.dtype, device=vec.device)
+                cached = self._coef_vec = (key, w)
+            return torch.dot(vec, cached[1])
         vals = list(losses.values())
         dt = vals[0].dtype
         for v in vals[1:]:
