@@ -44,10 +44,11 @@ int transoar_instnorm_relu_forward_parts(const void* x, const float* gamma, cons
                                          void* hip_stream);
 
 /* dx of the above; red_ws ends up holding, per (n,c), {sum g, sum g*xhat} with
- * g = dy * [relu active]: dbeta_c = sum_n red[n][c][0], dgamma_c = sum_n red[n][c][1]. */
+ * g = dy * [relu active]: dbeta_c = sum_n red[n][c][0], dgamma_c = sum_n red[n][c][1];
+ * dparams (2, C) fp32, optional (NULL: not written): row 0 = dbeta, row 1 = dgamma (ABI 3). */
 int transoar_instnorm_relu_backward(const void* x, const void* dy, const float* gamma,
                                     const float* beta, const float* mean_rstd, void* dx,
-                                    double* red_ws, int N, long V, int C, int relu,
+                                    double* red_ws, float* dparams, int N, long V, int C, int relu,
                                     void* hip_stream);
 
 int transoar_instnorm_abi_version(void);

@@ -232,9 +232,19 @@ __global__ __launch_bounds__(kINThreads) void instnorm_bwd_dx(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
     const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const double* __restrict__ red, unsigned short* __restrict__ dx, long V, int C, int blocks_per_sample,
-    int relu) {
+    int relu, float* __restrict__ dparams, int N) {
   const int chunks = C >> 3;
   const int n = blockIdx.x / blocks_per_sample, bi = blockIdx.x % blocks_per_sample;
+  if (dparams && blockIdx.x == 0) {
+    // the parameter gradients on the side: dbeta_c = sum_n red[n][c][0], dgamma_c = sum_n red[n][c][1] (a torch sum and two
+    // fp64 -> fp32 casts per layer otherwise: 36 launches of the step)
+    for (int i = threadIdx.x; i < 2 * C; i += kINThreads) {
+      const int k = i / C, c = i - k * C;
+      double s = 0.0;
+      for (int nn = 0; nn < N; ++nn) s += red[(static_cast<long>(nn) * C + c) * 2 + k];
+      dparams[i] = static_cast<float>(s);
+    }
+  }
   const int chunk = threadIdx.x % chunks;
   const long vstep = kINThreads / chunks;
   const long v_per_block = (V + blocks_per_sample - 1) / blocks_per_sample;
@@ -338,7 +348,7 @@ extern "C" int transoar_instnorm_relu_forward_parts(const void* x, const float* 
 }
 
 extern "C" int transoar_instnorm_relu_backward(const void* x, const void* dy, const float* gamma, const float* beta,
-                                               const float* mean_rstd, void* dx, double* red_ws, int N, long V,
+                                               const float* mean_rstd, void* dx, double* red_ws, float* dparams, int N, long V,
                                                int C, int relu, void* hip_stream) {
   const int rc = check(x, dy, N, V, C);
   if (rc) return rc;
@@ -352,8 +362,8 @@ extern "C" int transoar_instnorm_relu_backward(const void* x, const void* dy, co
                      beta, red_ws, V, C, bps, relu);
   hipLaunchKernelGGL(instnorm_bwd_dx, dim3(N * bps), dim3(kINThreads), 0, st, static_cast<const unsigned short*>(x),
                      static_cast<const unsigned short*>(dy), mean_rstd, gamma, beta, red_ws,
-                     static_cast<unsigned short*>(dx), V, C, bps, relu);
+                     static_cast<unsigned short*>(dx), V, C, bps, relu, dparams, N);
   return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int transoar_instnorm_abi_version(void) { return 2; }
+extern "C" int transoar_instnorm_abi_version(void) { return 3; }

@@ -22,9 +22,9 @@ def _load():
     lib.transoar_instnorm_relu_forward_parts.restype = i
     lib.transoar_instnorm_relu_forward_parts.argtypes = [p, p, p, p, p, i, p, p, i, lg, i, f, i, p]
     lib.transoar_instnorm_relu_backward.restype = i
-    lib.transoar_instnorm_relu_backward.argtypes = [p, p, p, p, p, p, p, i, lg, i, i, p]
+    lib.transoar_instnorm_relu_backward.argtypes = [p, p, p, p, p, p, p, p, i, lg, i, i, p]
     lib.transoar_instnorm_abi_version.restype = i
-    if lib.transoar_instnorm_abi_version() != 2:
+    if lib.transoar_instnorm_abi_version() != 3:
         raise _native.NativeLibraryError("%s: ABI mismatch, rebuild" % _LIB_PATH)
     return lib
 
@@ -74,13 +74,13 @@ class _InstNormReLU(torch.autograd.Function):
         dx = torch.empty_like(x, memory_format=CL3D)
         red = torch.empty((n, c, 2), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
+            dparams = torch.empty((2, c), dtype=torch.float32, device=x.device)      # dbeta | dgamma, summed over the samples by the kernel
             rc = lib.transoar_instnorm_relu_backward(x.data_ptr(), dy.data_ptr(), g32.data_ptr(), b32.data_ptr(),
-                                                     mean_rstd.data_ptr(), dx.data_ptr(), red.data_ptr(), n, v, c,
+                                                     mean_rstd.data_ptr(), dx.data_ptr(), red.data_ptr(), dparams.data_ptr(), n, v, c,
                                                      1 if ctx.relu else 0, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("transoar_instnorm_relu_backward failed with code %d" % rc)
-        sums = red.sum(0)
-        return dx, sums[:, 1].to(ctx.param_dtype), sums[:, 0].to(ctx.param_dtype), None, None, None
+        return dx, dparams[1].to(ctx.param_dtype), dparams[0].to(ctx.param_dtype), None, None, None
 
 
 def instance_norm_relu(x, gamma, beta, eps=1e-5, relu=True, part=None):
