@@ -207,6 +207,13 @@ C1_WGRAD_TR = os.environ.get("TRANSOAR_C1_WGRAD_TR", "1") != "0"
 C1_WGRAD_TR_PARTIALS = 1024         # persistent: 4 workgroups per CU
 
 
+def _colsum(partial):
+    """Sum of the workgroups' partial tiles (groups, ...) fp32 -> (prod of the rest,) in one launch of the short-matrix column-sum
+    kernel (torch's reduction needs 16-29 us for these)."""
+    flat = partial.view(partial.shape[0], -1)
+    return _rows.colsum_small(flat) if _rows.colsum_small_usable(flat) else flat.sum(0)
+
+
 def conv3d_c1_wgrad(x, gy):
     """x (N,1,D,H,W) bf16 contiguous, gy (N,Cout,D,H,W) bf16 NDHWC -> dW (Cout,1,3,3,3) fp32."""
     n, _, d, h, w = x.shape
@@ -217,7 +224,7 @@ def conv3d_c1_wgrad(x, gy):
     with torch.cuda.device(x.device):
         fn = lib.transoar_conv3d_c1_wgrad_tr if tr else lib.transoar_conv3d_c1_wgrad
         _check(fn(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), n_part, n, d, h, w, co, _stream()), "transoar_conv3d_c1_wgrad")
-    return partial.sum(0)[:co, :27].reshape(co, 1, 3, 3, 3)
+    return _colsum(partial).view(32, 32)[:co, :27].reshape(co, 1, 3, 3, 3)
 
 
 LDS_WGRAD_GROUPS = 512
@@ -240,7 +247,7 @@ def conv3d_k3_wgrad_lds(x, gy):
             with torch.cuda.device(x.device):
                 _check(fn(x.data_ptr(), gy.data_ptr(), partial.data_ptr(), groups, n, d, h, w, ci, co, ci0, ci_n, co0, co_n, _stream()),
                        "transoar_conv3d_k3_wgrad_lds")
-            dw[co0:co0 + co_n, ci0:ci0 + ci_n] = partial.sum(0)[:, :co_n, :ci_n].permute(1, 2, 0)
+            dw[co0:co0 + co_n, ci0:ci0 + ci_n] = _colsum(partial).view(27, 32, 32)[:, :co_n, :ci_n].permute(1, 2, 0)
     return dw.view(co, ci, 3, 3, 3)
 
 
@@ -333,7 +340,7 @@ class _Conv3dK3(torch.autograd.Function):
             gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g2 = gyb.permute(0, 2, 3, 4, 1).reshape(-1, gyb.shape[1])        # channels-last: a view, rows = voxels
-            gb = _rows.colsum(g2) if _rows.colsum_usable(g2) else gyb.float().sum(dim=(0, 2, 3, 4))
+            gb = _rows.colsum_any(g2) if g2.is_contiguous() else gyb.float().sum(dim=(0, 2, 3, 4))
         return gx, gw, gb, None, None, None
 
 
